@@ -1,0 +1,455 @@
+/*
+ * pcseg_oracle.c -- CPU restatement of the reference's per-frame hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is imported, linked or
+ * executed by the product (particle_col_image_segmentation_amd/); only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and only
+ * as the checker / the reported CPU baseline.
+ *
+ * The reference (ssilverman16/particle_col_image_segmentation) is pure Python;
+ * all of its pixel arithmetic lives in third-party packages that are not under
+ * /root/reference (pins from uv.lock: scikit-image 0.25.2, scipy 1.15.2).  Each
+ * function below restates the published algorithm of the library call the
+ * reference makes and cites that call site.  Parity is PINNED: every function is
+ * checked bit-for-bit against tests/golden (npz files), which were produced by
+ * running the real reference (tests/golden/make_golden.py) in the build
+ * container (scikit-image 0.18.3 / scipy 1.7.1 -- version skew documented in
+ * DESIGN.md).
+ *
+ * All images are single frames, row-major (H, W).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ A1 ---
+ * scipy.ndimage.median_filter(ds_arr, size=5)   tiff_analysis.py:122, 643
+ * mode='reflect' (d c b a | a b c d), rank 12 of the 25 window values. */
+static inline int reflect_idx(int i, int n)
+{
+    int p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - 1 - i;
+}
+
+void orc_median5_u8(const uint8_t *in, uint8_t *out, int H, int W)
+{
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            int hist[256];
+            memset(hist, 0, sizeof hist);
+            for (int dr = -2; dr <= 2; ++dr) {
+                int rr = reflect_idx(r + dr, H);
+                for (int dc = -2; dc <= 2; ++dc)
+                    hist[in[(size_t)rr * W + reflect_idx(c + dc, W)]]++;
+            }
+            int acc = 0, v = 0;
+            for (; v < 256; ++v) {
+                acc += hist[v];
+                if (acc >= 13) break;
+            }
+            out[(size_t)r * W + c] = (uint8_t)v;
+        }
+}
+
+/* ------------------------------------------------------------------ A2 ---
+ * skimage.measure.label(z_slice)            tiff_analysis.py:743, 260, 829
+ * skimage.measure.label(local_max)          refine_boundaries.py:64
+ * Components of equal-valued (equal_value=1) or non-zero (equal_value=0)
+ * pixels; value 0 is background; conn8 selects 8- vs 4-connectivity; labels
+ * 1..N numbered by the raster order of each component's first pixel. */
+int orc_label_i32(const int32_t *in, int32_t *out, int H, int W, int conn8, int equal_value)
+{
+    size_t n = (size_t)H * W;
+    memset(out, 0, n * sizeof(int32_t));
+    int32_t *stack = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
+    int next = 0;
+    static const int dr8[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+    static const int dc8[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+    static const int dr4[4] = {-1, 0, 0, 1};
+    static const int dc4[4] = {0, -1, 1, 0};
+    const int *dr = conn8 ? dr8 : dr4, *dc = conn8 ? dc8 : dc4;
+    int nn = conn8 ? 8 : 4;
+    for (size_t i = 0; i < n; ++i) {
+        if (in[i] == 0 || out[i] != 0) continue;
+        ++next;
+        int32_t v = in[i];
+        size_t sp = 0;
+        stack[sp++] = (int32_t)i;
+        out[i] = next;
+        while (sp) {
+            int32_t p = stack[--sp];
+            int r = p / W, c = p % W;
+            for (int k = 0; k < nn; ++k) {
+                int rr = r + dr[k], cc = c + dc[k];
+                if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+                size_t q = (size_t)rr * W + cc;
+                if (out[q] != 0 || in[q] == 0) continue;
+                if (equal_value && in[q] != v) continue;
+                out[q] = next;
+                stack[sp++] = (int32_t)q;
+            }
+        }
+    }
+    free(stack);
+    return next;
+}
+
+/* ------------------------------------------------------------------ A3 ---
+ * skimage.measure.regionprops(label_im) as consumed by the reference:
+ * area (tiff_analysis.py:769-781), centroid (:406,844,1054), bbox (:860-863),
+ * coords[0] / get_type (:1041-1044).  Integer sums only; the one float64
+ * divide per centroid happens in the caller.
+ * table[l-1] = {area, sum_r, sum_c, minr, minc, maxr+1, maxc+1, first_linear_index} */
+void orc_region_table(const int32_t *labels, int H, int W, int N, int64_t *table)
+{
+    for (int l = 0; l < N; ++l) {
+        int64_t *t = table + (size_t)l * 8;
+        t[0] = t[1] = t[2] = 0;
+        t[3] = H; t[4] = W; t[5] = 0; t[6] = 0; t[7] = -1;
+    }
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            int32_t l = labels[(size_t)r * W + c];
+            if (l <= 0 || l > N) continue;
+            int64_t *t = table + (size_t)(l - 1) * 8;
+            t[0] += 1; t[1] += r; t[2] += c;
+            if (r < t[3]) t[3] = r;
+            if (c < t[4]) t[4] = c;
+            if (r + 1 > t[5]) t[5] = r + 1;
+            if (c + 1 > t[6]) t[6] = c + 1;
+            if (t[7] < 0) t[7] = (int64_t)r * W + c;
+        }
+}
+
+/* ------------------------------------------------------------------ M1 ---
+ * Per-ROI isotope sums  S_k = sum(raw_k .* roimask)    .m:122-135, 186-199
+ * sums[(l-1)*C + k], float64 accumulation in raster order. */
+void orc_channel_sums(const int32_t *labels, const float *planes, int C, int H, int W, int N, double *sums)
+{
+    size_t n = (size_t)H * W;
+    for (size_t i = 0; i < (size_t)N * C; ++i) sums[i] = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        int32_t l = labels[i];
+        if (l <= 0 || l > N) continue;
+        for (int k = 0; k < C; ++k) sums[(size_t)(l - 1) * C + k] += (double)planes[(size_t)k * n + i];
+    }
+}
+
+/* --------------------------------------------------------------- A6/A8 ---
+ * skimage.morphology.binary_dilation(mask, disk(r))   tiff_analysis.py:827-828, 990
+ * disk(r) = {x^2+y^2 <= r^2}; outside the image counts as False.  Brute force
+ * on purpose: it validates the identity dilate(m, disk(r)) == (EDT^2(~m) <= r^2)
+ * that the product uses. */
+void orc_dilate_disk(const uint8_t *mask, uint8_t *out, int H, int W, int rad)
+{
+    memset(out, 0, (size_t)H * W);
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            if (!mask[(size_t)r * W + c]) continue;
+            for (int dr = -rad; dr <= rad; ++dr) {
+                int rr = r + dr;
+                if (rr < 0 || rr >= H) continue;
+                for (int dc = -rad; dc <= rad; ++dc) {
+                    int cc = c + dc;
+                    if (cc < 0 || cc >= W) continue;
+                    if (dr * dr + dc * dc <= rad * rad) out[(size_t)rr * W + cc] = 1;
+                }
+            }
+        }
+}
+
+/* ------------------------------------------------------------------ R2 ---
+ * scipy.ndimage.distance_transform_edt(mask)  refine_boundaries.py:60,
+ * tiff_analysis.py:996.  Exact integer squared distance to the nearest False
+ * pixel (Meijster's two-scan algorithm, integer Sep); the float64 result is
+ * sqrt((double)d2) in the caller.  An image with no False pixel at all behaves
+ * in scipy (1.7.1 and 1.15.3) as if one background pixel sat at (-1, 0). */
+void orc_edt_sq(const uint8_t *mask, int32_t *d2, int H, int W)
+{
+    const int64_t INF = (int64_t)1 << 24;
+    size_t n = (size_t)H * W;
+    int any_bg = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (!mask[i]) { any_bg = 1; break; }
+    if (!any_bg) {
+        for (int r = 0; r < H; ++r)
+            for (int c = 0; c < W; ++c)
+                d2[(size_t)r * W + c] = (r + 1) * (r + 1) + c * c;
+        return;
+    }
+    int64_t *g = (int64_t *)malloc((n ? n : 1) * sizeof(int64_t));
+    for (int c = 0; c < W; ++c) {
+        int64_t d = INF;
+        for (int r = 0; r < H; ++r) {
+            d = mask[(size_t)r * W + c] ? (d >= INF ? INF : d + 1) : 0;
+            g[(size_t)r * W + c] = d;
+        }
+        d = INF;
+        for (int r = H - 1; r >= 0; --r) {
+            d = mask[(size_t)r * W + c] ? (d >= INF ? INF : d + 1) : 0;
+            if (d < g[(size_t)r * W + c]) g[(size_t)r * W + c] = d;
+        }
+    }
+    int *s = (int *)malloc((size_t)(W + 1) * sizeof(int));
+    int *t = (int *)malloc((size_t)(W + 1) * sizeof(int));
+    for (int r = 0; r < H; ++r) {
+        const int64_t *gr = g + (size_t)r * W;
+#define F(x, i) (((int64_t)(x) - (i)) * ((int64_t)(x) - (i)) + gr[i] * gr[i])
+        int q = 0;
+        s[0] = 0; t[0] = 0;
+        for (int u = 1; u < W; ++u) {
+            while (q >= 0 && F(t[q], s[q]) > F(t[q], u)) --q;
+            if (q < 0) { q = 0; s[0] = u; }
+            else {
+                int64_t i = s[q];
+                int64_t num = (int64_t)u * u - i * i + gr[u] * gr[u] - gr[i] * gr[i];
+                int64_t den = 2 * ((int64_t)u - i);
+                int64_t sep = num >= 0 ? num / den : -((-num + den - 1) / den); /* floor */
+                int64_t w = 1 + sep;
+                if (w < W) { ++q; s[q] = u; t[q] = (int)(w < 0 ? 0 : w); }
+            }
+        }
+        for (int u = W - 1; u >= 0; --u) {
+            d2[(size_t)r * W + u] = (int32_t)F(u, s[q]);
+            if (u == t[q]) --q;
+        }
+#undef F
+    }
+    free(s); free(t); free(g);
+}
+
+/* brute-force EDT^2 for cross-checking orc_edt_sq on small images */
+void orc_edt_sq_brute(const uint8_t *mask, int32_t *d2, int H, int W)
+{
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            int64_t best = -1;
+            if (!mask[(size_t)r * W + c]) best = 0;
+            else
+                for (int rr = 0; rr < H; ++rr)
+                    for (int cc = 0; cc < W; ++cc)
+                        if (!mask[(size_t)rr * W + cc]) {
+                            int64_t d = (int64_t)(r - rr) * (r - rr) + (int64_t)(c - cc) * (c - cc);
+                            if (best < 0 || d < best) best = d;
+                        }
+            if (best < 0) best = (int64_t)(r + 1) * (r + 1) + (int64_t)c * c;
+            d2[(size_t)r * W + c] = (int32_t)best;
+        }
+}
+
+/* ------------------------------------------------------------------ A7 ---
+ * scipy.ndimage.binary_fill_holes(merged_image)   tiff_analysis.py:880
+ * holes = background components (4-connectivity) not touching the border. */
+void orc_fill_holes(const uint8_t *mask, uint8_t *out, int H, int W)
+{
+    size_t n = (size_t)H * W;
+    uint8_t *reach = (uint8_t *)calloc(n ? n : 1, 1);
+    int32_t *stack = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
+    size_t sp = 0;
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c)
+            if ((r == 0 || c == 0 || r == H - 1 || c == W - 1) && !mask[(size_t)r * W + c] && !reach[(size_t)r * W + c]) {
+                reach[(size_t)r * W + c] = 1;
+                stack[sp++] = r * W + c;
+            }
+    while (sp) {
+        int32_t p = stack[--sp];
+        int r = p / W, c = p % W;
+        static const int dr[4] = {-1, 0, 0, 1}, dc[4] = {0, -1, 1, 0};
+        for (int k = 0; k < 4; ++k) {
+            int rr = r + dr[k], cc = c + dc[k];
+            if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+            size_t q = (size_t)rr * W + cc;
+            if (mask[q] || reach[q]) continue;
+            reach[q] = 1;
+            stack[sp++] = (int32_t)q;
+        }
+    }
+    for (size_t i = 0; i < n; ++i) out[i] = (uint8_t)(mask[i] || !reach[i]);
+    free(reach); free(stack);
+}
+
+/* ------------------------------------------------------------------ R3 ---
+ * skimage.morphology.local_maxima(distance)    refine_boundaries.py:63
+ * A maximal 8-connected set of equal-valued pixels is a maximum iff no
+ * 8-neighbour of the set is strictly higher; the image is padded with its
+ * minimum, so border plateaus are allowed but an all-constant image has no
+ * maximum (skimage/morphology/extrema.py:388-391). */
+void orc_local_maxima_f64(const double *img, uint8_t *out, int H, int W)
+{
+    size_t n = (size_t)H * W;
+    memset(out, 0, n);
+    if (n == 0) return;
+    int constant = 1;
+    for (size_t i = 1; i < n; ++i)
+        if (img[i] != img[0]) { constant = 0; break; }
+    if (constant) return;
+    uint8_t *seen = (uint8_t *)calloc(n, 1);
+    int32_t *stack = (int32_t *)malloc(n * sizeof(int32_t));
+    int32_t *members = (int32_t *)malloc(n * sizeof(int32_t));
+    for (size_t i = 0; i < n; ++i) {
+        if (seen[i]) continue;
+        double v = img[i];
+        size_t sp = 0, nm = 0;
+        int is_max = 1;
+        stack[sp++] = (int32_t)i;
+        seen[i] = 1;
+        while (sp) {
+            int32_t p = stack[--sp];
+            members[nm++] = p;
+            int r = p / W, c = p % W;
+            for (int dr = -1; dr <= 1; ++dr)
+                for (int dc = -1; dc <= 1; ++dc) {
+                    if (!dr && !dc) continue;
+                    int rr = r + dr, cc = c + dc;
+                    if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+                    size_t q = (size_t)rr * W + cc;
+                    if (img[q] > v) is_max = 0;
+                    else if (img[q] == v && !seen[q]) { seen[q] = 1; stack[sp++] = (int32_t)q; }
+                }
+        }
+        if (is_max)
+            for (size_t k = 0; k < nm; ++k) out[members[k]] = 1;
+    }
+    free(seen); free(stack); free(members);
+}
+
+/* ------------------------------------------------------------------ W1 ---
+ * skimage.segmentation.watershed(boundary_map, markers, mask=binary_mask)
+ *                                               refine_boundaries.py:73
+ * connectivity 1 (4-neighbours, visited in the order up, left, right, down),
+ * no compactness, no watershed line.  Sequential priority flood on
+ * (value, age) with strict less-than; all seeds enter with age 0 in raster
+ * order; a pixel is labelled when it is PUSHED; the priority is the raw pixel
+ * value.  The queue is an array binary heap whose sift-up / sift-down are
+ * restated exactly, because its layout decides the order of seeds with equal
+ * value (skimage/segmentation/_watershed.py:84-91, 209-228 and the package's
+ * heap_general). */
+typedef struct { double value; int32_t age; int32_t index; } orc_item;
+
+static inline int orc_smaller(const orc_item *a, const orc_item *b)
+{
+    if (a->value != b->value) return a->value < b->value;
+    return a->age < b->age;
+}
+
+void orc_watershed(const double *img, const int32_t *markers, const uint8_t *mask, int32_t *out, int H, int W)
+{
+    size_t n = (size_t)H * W;
+    orc_item *heap = (orc_item *)malloc((n ? n : 1) * sizeof(orc_item));
+    size_t items = 0;
+    int32_t age = 0;
+    for (size_t i = 0; i < n; ++i) out[i] = mask[i] ? markers[i] : 0;
+#define PUSH(V, A, I)                                                   \
+    do {                                                                \
+        size_t child = items++;                                         \
+        heap[child].value = (V); heap[child].age = (A); heap[child].index = (I); \
+        while (child > 0) {                                             \
+            size_t parent = (child + 1) / 2 - 1;                        \
+            if (orc_smaller(&heap[child], &heap[parent])) {             \
+                orc_item tmp = heap[child]; heap[child] = heap[parent]; heap[parent] = tmp; \
+                child = parent;                                         \
+            } else break;                                               \
+        }                                                               \
+    } while (0)
+    for (size_t i = 0; i < n; ++i)
+        if (out[i] != 0) PUSH(img[i], 0, (int32_t)i);
+    while (items > 0) {
+        orc_item e = heap[0];
+        heap[0] = heap[items - 1];
+        --items;
+        size_t i = 0;
+        for (;;) {
+            size_t l = 2 * i + 1, r = 2 * i + 2, smallest = i;
+            if (l < items) {
+                if (orc_smaller(&heap[l], &heap[i])) smallest = l;
+                if (r < items && orc_smaller(&heap[r], &heap[smallest])) smallest = r;
+            } else break;
+            if (smallest != i) {
+                orc_item tmp = heap[i]; heap[i] = heap[smallest]; heap[smallest] = tmp;
+                i = smallest;
+            } else break;
+        }
+        int r0 = e.index / W, c0 = e.index % W;
+        static const int dr[4] = {-1, 0, 0, 1}, dc[4] = {0, -1, 1, 0};
+        for (int k = 0; k < 4; ++k) {
+            int rr = r0 + dr[k], cc = c0 + dc[k];
+            if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+            size_t q = (size_t)rr * W + cc;
+            if (!mask[q] || out[q] != 0) continue;
+            ++age;
+            out[q] = out[e.index];
+            PUSH(img[q], age, (int32_t)q);
+        }
+    }
+#undef PUSH
+    free(heap);
+}
+
+/* ------------------------------------------------------------------ X1 ---
+ * skimage.filters.threshold_otsu(image, nbins=256) -- north_star extension,
+ * no reference call site (refine_boundaries.py:22 imports filters, never uses
+ * it): PARITY UNPINNED BY THE REFERENCE; restated from scikit-image 0.18.3:
+ * histogram over [min,max] with 256 equal bins, bin centres, between-class
+ * variance maximised over the split index, threshold = centre of that bin.
+ * hist[256] is returned for the caller's checks. */
+double orc_otsu_f32(const float *img, size_t n, int64_t *hist)
+{
+    float lo = img[0], hi = img[0];
+    for (size_t i = 1; i < n; ++i) { if (img[i] < lo) lo = img[i]; if (img[i] > hi) hi = img[i]; }
+    for (int b = 0; b < 256; ++b) hist[b] = 0;
+    if (lo == hi) { hist[0] = (int64_t)n; return (double)lo; }
+    /* numpy.histogram: bin = floor((x - lo) / (hi - lo) * 256) in float64, with edge corrections */
+    double dlo = (double)lo, dhi = (double)hi, norm = 256.0 / (dhi - dlo);
+    for (size_t i = 0; i < n; ++i) {
+        double x = (double)img[i];
+        int b = (int)((x - dlo) * norm);
+        if (b >= 256) b = 255;
+        /* numpy corrects indices against the float64 edges */
+        double e0 = dlo + (dhi - dlo) * ((double)b / 256.0);
+        double e1 = dlo + (dhi - dlo) * ((double)(b + 1) / 256.0);
+        if (x < e0 && b > 0) --b;
+        else if (x >= e1 && b < 255) ++b;
+        hist[b]++;
+    }
+    double best = -1.0, thr = dlo;
+    double w1 = 0.0, s1 = 0.0, wt = 0.0, st = 0.0;
+    double centers[256];
+    for (int b = 0; b < 256; ++b) {
+        double e0 = dlo + (dhi - dlo) * ((double)b / 256.0);
+        double e1 = dlo + (dhi - dlo) * ((double)(b + 1) / 256.0);
+        centers[b] = (e0 + e1) / 2.0;
+        wt += (double)hist[b]; st += (double)hist[b] * centers[b];
+    }
+    for (int b = 0; b < 255; ++b) {
+        w1 += (double)hist[b]; s1 += (double)hist[b] * centers[b];
+        double w2 = wt - w1;
+        if (w1 == 0.0 || w2 == 0.0) continue;
+        double m1 = s1 / w1, m2 = (st - s1) / w2;
+        double var = w1 * w2 * (m1 - m2) * (m1 - m2);
+        if (var > best) { best = var; thr = centers[b]; }
+    }
+    return thr;
+}
+
+/* ------------------------------------------------------------------ X2 ---
+ * 3x3 binary erosion / dilation (square footprint) -- north_star extension, no
+ * reference call site: PARITY UNPINNED BY THE REFERENCE.  Dilation: outside =
+ * False; erosion: outside = True (skimage/morphology/binary.py border_value). */
+void orc_morph3x3(const uint8_t *mask, uint8_t *out, int H, int W, int erode)
+{
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            int acc = erode ? 1 : 0;
+            for (int dr = -1; dr <= 1; ++dr)
+                for (int dc = -1; dc <= 1; ++dc) {
+                    int rr = r + dr, cc = c + dc;
+                    int v = (rr < 0 || rr >= H || cc < 0 || cc >= W) ? (erode ? 1 : 0) : (mask[(size_t)rr * W + cc] != 0);
+                    if (erode) acc &= v; else acc |= v;
+                }
+            out[(size_t)r * W + c] = (uint8_t)acc;
+        }
+}
