@@ -1,0 +1,185 @@
+/*
+ * pcseg.h -- C ABI of libpcseg.so, the MI355X (gfx950) implementation of the
+ * per-frame segmentation hot path of ssilverman16/particle_col_image_segmentation.
+ *
+ * The reference has NO FFI of its own (it is pure Python calling scipy /
+ * scikit-image); each entry point below replaces the library call or loop the
+ * reference makes at the cited file:line.  The Python host layer
+ * (particle_col_image_segmentation_amd/) binds these with ctypes; the stub a
+ * reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every image argument is a DEVICE pointer to a contiguous batch-major,
+ *     row-major array (B, H, W) or (B, C, H, W); buffers are caller-owned
+ *     (torch tensors' data_ptr()); the library allocates nothing persistent;
+ *   - scratch comes from a caller-provided workspace sized by the matching
+ *     *_workspace_bytes(B, H, W) query (256-byte aligned device memory);
+ *   - work is enqueued on `stream` (a hipStream_t); functions marked [sync]
+ *     also wait on that stream because a host-side convergence loop drives
+ *     them, every other function is asynchronous;
+ *   - return value: PCSEG_OK or a negative pcseg_status; the message is in
+ *     pcseg_last_error() (thread local);
+ *   - there is no CPU fallback anywhere: without a HIP device every compute
+ *     entry point returns PCSEG_ERR_HIP.
+ */
+#ifndef PCSEG_H
+#define PCSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *pcseg_stream_t; /* hipStream_t */
+
+enum pcseg_status {
+    PCSEG_OK = 0,
+    PCSEG_ERR_ARG = -1,       /* bad shape / null pointer / unsupported size */
+    PCSEG_ERR_HIP = -2,       /* a HIP call or launch failed */
+    PCSEG_ERR_WORKSPACE = -3, /* workspace too small */
+    PCSEG_ERR_CAPACITY = -4   /* more labels than the caller's table capacity */
+};
+
+/* layout of one row of the region table (int64 each) -- skimage regionprops
+ * fields the reference consumes: area (tiff_analysis.py:769-781), centroid sums
+ * (:406,844,1054), bbox half-open (:860-863), raster-first pixel (:1041-1044) */
+enum pcseg_region_col {
+    PCSEG_R_AREA = 0, PCSEG_R_SUM_ROW = 1, PCSEG_R_SUM_COL = 2,
+    PCSEG_R_MIN_ROW = 3, PCSEG_R_MIN_COL = 4, PCSEG_R_MAX_ROW1 = 5, PCSEG_R_MAX_COL1 = 6,
+    PCSEG_R_FIRST = 7, PCSEG_R_NCOLS = 8
+};
+
+int pcseg_version(void);
+const char *pcseg_last_error(void);
+int pcseg_device_count(void);
+
+/* ---- ingest: class map = argmax over the C planes + 1 (what ilastik's
+ * "Simple Segmentation" export holds; read at tiff_analysis.py:118-121, 639-642) */
+int pcseg_argmax_planes_f32(const float *stack, uint8_t *cls, int B, int C, int H, int W, pcseg_stream_t stream);
+
+/* ---- A1: scipy.ndimage.median_filter(ds_arr, size=5), mode='reflect'
+ * (tiff_analysis.py:122, 643) */
+int pcseg_median5_u8(const uint8_t *in, uint8_t *out, int B, int H, int W, pcseg_stream_t stream);
+
+/* ---- A2: skimage.measure.label (tiff_analysis.py:743, 260, 829;
+ * refine_boundaries.py:64) and scipy.ndimage.label (inside binary_fill_holes).
+ * labels: int32 (B,H,W), 0 = background, 1..N in raster order of each
+ * component's first pixel; counts[b] = N of frame b (device int32[B]). */
+size_t pcseg_ccl_workspace_bytes(int B, int H, int W);
+int pcseg_ccl8_equal_u8(const uint8_t *in, int32_t *labels, int32_t *counts, int B, int H, int W,
+                        void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+int pcseg_ccl8_bool(const uint8_t *in, int32_t *labels, int32_t *counts, int B, int H, int W,
+                    void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+int pcseg_ccl4_bool(const uint8_t *in, int32_t *labels, int32_t *counts, int B, int H, int W,
+                    void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+/* renumber a root image (value = linear index of the component's first pixel
+ * + 1, 0 = background) into 1..N raster order; `labels` must not alias `roots`. */
+int pcseg_compact_labels(const int32_t *roots, int32_t *labels, int32_t *counts, int B, int H, int W,
+                         void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
+/* ---- A3 + M1: regionprops fields and per-ROI isotope sums
+ * (tiff_analysis.py:746-773, 1041-1044; .m:122-135, 186-199).
+ * stats: int64 (B, cap, 8) rows as pcseg_region_col; cls_out: uint8 (B, cap) =
+ * class-map value at the raster-first pixel (NULL if cls is NULL); sums:
+ * float64 (B, cap, C) (NULL if planes is NULL).  Labels above cap are dropped
+ * and overflow[b] (device int32[B], may be NULL) is set. */
+int pcseg_region_reduce(const int32_t *labels, const uint8_t *cls, const float *planes, int C,
+                        int B, int H, int W, int cap, int64_t *stats, uint8_t *cls_out, double *sums,
+                        int32_t *overflow, pcseg_stream_t stream);
+/* same, but only rows l < counts[b] (device int32[B], e.g. from pcseg_ccl*) are
+ * initialised and filled; rows beyond are left untouched. */
+int pcseg_region_reduce_n(const int32_t *labels, const int32_t *counts, const uint8_t *cls, const float *planes,
+                          int C, int B, int H, int W, int cap, int64_t *stats, uint8_t *cls_out, double *sums,
+                          int32_t *overflow, pcseg_stream_t stream);
+
+/* ---- R1: binary_mask = boundary_map < threshold (refine_boundaries.py:44-45) */
+int pcseg_threshold_lt_f32(const float *img, float threshold, uint8_t *mask, int B, int H, int W,
+                           pcseg_stream_t stream);
+
+/* ---- R2: scipy.ndimage.distance_transform_edt as exact integer squared
+ * distance to the nearest zero pixel (refine_boundaries.py:60,
+ * tiff_analysis.py:996); the float64 distance is sqrt((double)d2).  cap < 0:
+ * exact everywhere; cap >= 0: values above cap are reported as cap + 1.  A
+ * frame without any zero pixel follows scipy: virtual zero pixel at (-1, 0). */
+size_t pcseg_edt_workspace_bytes(int B, int H, int W);
+int pcseg_edt_sq_u8(const uint8_t *mask, int32_t *d2, int B, int H, int W, int cap,
+                    void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+/* fused R1 + R2: mask = img < threshold (also written to mask_out if not NULL) */
+int pcseg_edt_sq_lt_f32(const float *img, float threshold, int32_t *d2, uint8_t *mask_out,
+                        int B, int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
+/* ---- A6: skimage.morphology.binary_dilation(binary, disk(radius))
+ * (tiff_analysis.py:827-828, 990) with binary = ((value_bits >> in) & 1),
+ * i.e. `z_slice == v` for one bit and the OR of several classes for several
+ * (tiff_analysis.py:812, 816-818); out is 0/1. */
+int pcseg_dilate_disk_u8(const uint8_t *in, uint64_t value_bits, int radius, uint8_t *out,
+                         int B, int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
+/* ---- A8: fill_particle_area (tiff_analysis.py:982-1015) in one pass pair:
+ * out = ds with overlap pixels set to overlap_label, where overlap =
+ * (ds == cell_label) & (EDT(ds != particle) < dist_threshold | dilate(ds ==
+ * particle, disk(dilation_radius))); overlap_area[b] += count (device int64[B]). */
+int pcseg_fill_particle(const uint8_t *ds, uint8_t *out, int particle_label, int cell_label,
+                        int overlap_label, int dilation_radius, int dist_threshold, int64_t *overlap_area,
+                        int B, int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
+/* ---- A7: scipy.ndimage.binary_fill_holes (tiff_analysis.py:880) */
+size_t pcseg_fill_holes_workspace_bytes(int B, int H, int W);
+int pcseg_fill_holes(const uint8_t *mask, uint8_t *out, int B, int H, int W,
+                     void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
+/* ---- R3 + R4: skimage.morphology.local_maxima(distance) and
+ * measure.label(local_max) (refine_boundaries.py:63-64) on an int32 image
+ * (d2 is order-isomorphic to the float64 distance).  is_max: uint8 (NULL to
+ * skip); markers: int32 1..K raster order (NULL to skip); counts: int32[B]. */
+size_t pcseg_local_maxima_workspace_bytes(int B, int H, int W);
+int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers, int32_t *counts,
+                           int B, int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
+/* ---- W1: skimage.segmentation.watershed(image, markers, mask=mask),
+ * connectivity 1, no compactness, no watershed line (refine_boundaries.py:73).
+ * [sync]  mode 0: parallel flood + proof check, frames that fail the check
+ * are re-run by the exact sequential priority flood; mode 1: exact sequential
+ * flood for every frame; mode 2: parallel flood only (tie_flags tells which
+ * frames are NOT proven exact).  tie_flags: device int32[B] (may be NULL). */
+size_t pcseg_watershed_workspace_bytes(int B, int H, int W);
+int pcseg_watershed4_f32(const float *img, const int32_t *markers, const uint8_t *mask, int32_t *out,
+                         int32_t *tie_flags, int B, int H, int W, int mode,
+                         void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
+/* ---- A6 tail: get_merged_regions grouping (tiff_analysis.py:843-878).
+ * For frame b and region r < n_regions[b] with select[b][r] != 0: key =
+ * dilated_labels at the truncated centroid; regions sharing a non-zero key
+ * form one group, groups numbered 1.. in the order of their first member;
+ * group_of[b][r] = group id or 0 (unselected / key 0).  n_groups: int32[B].
+ * stats is the (B, cap, 8) table of pcseg_region_reduce. */
+size_t pcseg_merge_groups_workspace_bytes(int B, int cap);
+int pcseg_merge_groups(const int32_t *dilated_labels, const int64_t *stats, const uint8_t *select,
+                       const int32_t *n_regions, int32_t *group_of, int32_t *n_groups,
+                       int B, int H, int W, int cap, void *workspace, size_t workspace_bytes,
+                       pcseg_stream_t stream);
+
+/* ---- C6: combine_cell_positions_and_clusters (tiff_analysis.py:252-287):
+ * out = dapi with every 8-connected component of (dapi == 1) whose overlap
+ * with (other == 1) exceeds `threshold` of its area set to 2. */
+size_t pcseg_overlap_workspace_bytes(int B, int H, int W);
+int pcseg_remove_overlapping(const uint8_t *dapi, const uint8_t *other, double threshold, uint8_t *out,
+                             int B, int H, int W, void *workspace, size_t workspace_bytes,
+                             pcseg_stream_t stream);
+
+/* ---- X1 (north_star extension, no reference call site): 256-bin histogram of
+ * each frame over its own [min, max] (device int64 (B,256), float32 (B,2)
+ * lo/hi); the between-class-variance argmax is a 256-element host epilogue. */
+int pcseg_otsu_hist_f32(const float *img, int64_t *hist, float *lohi, int B, int H, int W,
+                        pcseg_stream_t stream);
+
+/* ---- X2 (north_star extension, no reference call site): 3x3 square binary
+ * erosion (erode != 0, outside = True) or dilation (outside = False). */
+int pcseg_morph3x3(const uint8_t *mask, uint8_t *out, int erode, int B, int H, int W, pcseg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCSEG_H */

@@ -1,0 +1,637 @@
+// Connected-component labelling (A2) and everything built on it: raster-order
+// label compaction (K2c), binary_fill_holes (A7), plateau-aware local maxima +
+// marker numbering (R3/R4) and the DAPI/RFP overlap removal (C6).
+//
+// Union-find with "root = smallest linear index": a tile-local pass in LDS
+// (64x32 pixels per 256-thread block, row runs pre-linked without atomics,
+// vertical / diagonal links only where they are not implied by a run), one
+// global pass over tile borders with agent-scope atomicMin, one flatten pass.
+// Because the root of a component is its raster-first pixel, skimage's label
+// numbering is the rank of the root among all roots: wave ballot/popcount +
+// block scan + one exclusive scan of the block totals.
+#include "common.h"
+
+namespace pcseg {
+
+constexpr int CCL_TW = 64, CCL_TH = 32, CCL_TILE = CCL_TW * CCL_TH;
+constexpr int SCAN_PIX = 1024;  // pixels per block in the count / assign / relabel passes
+
+// ---- key functors: 0 = background, equal non-zero keys connect
+struct KeyEqU8 {
+    const uint8_t *p;
+    __device__ __forceinline__ int operator()(int64_t i) const { return p[i]; }
+};
+struct KeyNzU8 {
+    const uint8_t *p;
+    __device__ __forceinline__ int operator()(int64_t i) const { return p[i] != 0; }
+};
+struct KeyZeroU8 {  // background components (fill holes)
+    const uint8_t *p;
+    __device__ __forceinline__ int operator()(int64_t i) const { return p[i] == 0; }
+};
+struct KeyIsOneU8 {  // dapi == 1
+    const uint8_t *p;
+    __device__ __forceinline__ int operator()(int64_t i) const { return p[i] == 1; }
+};
+struct KeyI32 {
+    const int32_t *p;
+    __device__ __forceinline__ int operator()(int64_t i) const { return p[i]; }
+};
+
+// ---- LDS union-find
+__device__ __forceinline__ int find_lds(volatile int *par, int x)
+{
+    int p;
+    while ((p = par[x]) != x) x = p;
+    return x;
+}
+__device__ __forceinline__ void unite_lds(int *par, int a, int b)
+{
+    for (;;) {
+        a = find_lds(par, a);
+        b = find_lds(par, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(&par[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// ---- global union-find (parents only ever decrease; stale reads cost iterations, never correctness)
+__device__ __forceinline__ int find_glb(const int *par, int x)
+{
+    int p;
+    while ((p = ld_agent(par + x)) != x) x = p;
+    return x;
+}
+__device__ __forceinline__ void unite_glb(int *par, int a, int b)
+{
+    for (;;) {
+        a = find_glb(par, a);
+        b = find_glb(par, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(par + a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+template <typename KeyFn, bool CONN8>
+__global__ void __launch_bounds__(256) ccl_tile_kernel(KeyFn keyfn, int *__restrict__ parent, int H, int W)
+{
+    __shared__ int key[CCL_TILE];
+    __shared__ int par[CCL_TILE];
+    const int b = blockIdx.z, r0 = blockIdx.y * CCL_TH, c0 = blockIdx.x * CCL_TW;
+    const int64_t fbase = (int64_t)b * H * W;
+    for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
+        int r = r0 + i / CCL_TW, c = c0 + i % CCL_TW;
+        key[i] = (r < H && c < W) ? keyfn(fbase + (int64_t)r * W + c) : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
+        int k = key[i], lc = i % CCL_TW;
+        par[i] = k == 0 ? -1 : ((lc > 0 && key[i - 1] == k) ? i - 1 : i);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
+        int k = key[i], lc = i % CCL_TW;
+        if (k == 0 || i < CCL_TW) continue;
+        bool w = lc > 0 && key[i - 1] == k;
+        bool n = key[i - CCL_TW] == k;
+        bool nw = lc > 0 && key[i - CCL_TW - 1] == k;
+        if (n && !(w && nw)) unite_lds(par, i, i - CCL_TW);
+        if (CONN8) {
+            bool ne = lc < CCL_TW - 1 && key[i - CCL_TW + 1] == k;
+            if (ne && !n) unite_lds(par, i, i - CCL_TW + 1);
+            if (nw && !n && !w) unite_lds(par, i, i - CCL_TW - 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
+        int r = r0 + i / CCL_TW, c = c0 + i % CCL_TW;
+        if (r >= H || c >= W) continue;
+        int v = -1;
+        if (key[i] != 0) {
+            int root = find_lds(par, i);
+            v = (r0 + root / CCL_TW) * W + c0 + root % CCL_TW;
+        }
+        parent[fbase + (int64_t)r * W + c] = v;
+    }
+}
+
+template <typename KeyFn, bool CONN8>
+__global__ void __launch_bounds__(256) ccl_border_kernel(KeyFn keyfn, int *__restrict__ parent, int H, int W)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= H || c >= W) return;
+    const bool top = (r % CCL_TH) == 0 && r > 0;
+    const bool left = (c % CCL_TW) == 0 && c > 0;
+    const bool right = (c % CCL_TW) == CCL_TW - 1 && c + 1 < W;
+    if (!top && !left && !(CONN8 && right && r > 0)) return;
+    const int64_t fbase = (int64_t)blockIdx.z * H * W;
+    int *par = parent + fbase;
+    const int p = r * W + c;
+    const int k = keyfn(fbase + p);
+    if (k == 0) return;
+    if (left && keyfn(fbase + p - 1) == k) unite_glb(par, p, p - 1);
+    if (r > 0) {
+        if (top && keyfn(fbase + p - W) == k) unite_glb(par, p, p - W);
+        if (CONN8) {
+            if (c > 0 && (top || left) && keyfn(fbase + p - W - 1) == k) unite_glb(par, p, p - W - 1);
+            if (c + 1 < W && (top || right) && keyfn(fbase + p - W + 1) == k) unite_glb(par, p, p - W + 1);
+        }
+    }
+}
+
+// flatten + count roots accepted by `pred` per SCAN_PIX block
+struct PredAll {
+    __device__ __forceinline__ bool operator()(int64_t) const { return true; }
+};
+struct PredNotFlagged {  // root accepted unless flag[root] != 0
+    const uint8_t *flag;
+    __device__ __forceinline__ bool operator()(int64_t gi) const { return flag[gi] == 0; }
+};
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int *total)
+{
+    // 256 threads = 4 waves; returns exclusive prefix of v, *total = block sum
+    __shared__ int wsum[4];
+    int lane = lane_id(), wid = threadIdx.x >> 6;
+    int inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wid) base += wsum[w];
+        tot += wsum[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+template <typename Pred>
+__global__ void __launch_bounds__(256) ccl_flatten_count_kernel(int *__restrict__ parent, int *__restrict__ blockcount,
+                                                                 Pred pred, int64_t n, int nblk, bool flatten)
+{
+    const int b = blockIdx.y;
+    int *par = parent + (int64_t)b * n;
+    int cnt = 0;
+    int64_t i0 = (int64_t)blockIdx.x * SCAN_PIX + threadIdx.x * 4;
+    for (int j = 0; j < 4; ++j) {
+        int64_t i = i0 + j;
+        if (i >= n) break;
+        int p = par[i];
+        if (p < 0) continue;
+        if (flatten) {
+            int x = p, q;
+            while ((q = par[x]) != x) x = q;
+            if (x != p) par[i] = x;
+            p = x;
+        }
+        if (p == (int)i && pred((int64_t)b * n + i)) ++cnt;
+    }
+    int total;
+    block_exclusive_scan(cnt, &total);
+    if (threadIdx.x == 0) blockcount[b * nblk + blockIdx.x] = total;
+}
+
+// one block per frame: exclusive scan of the block totals, frame total -> counts
+__global__ void __launch_bounds__(256) ccl_scan_blocks_kernel(int *__restrict__ blockcount, int *__restrict__ counts, int nblk)
+{
+    int *bc = blockcount + (int64_t)blockIdx.x * nblk;
+    int carry = 0;
+    for (int base = 0; base < nblk; base += 256) {
+        int i = base + threadIdx.x;
+        int v = i < nblk ? bc[i] : 0;
+        int total;
+        int ex = block_exclusive_scan(v, &total);
+        if (i < nblk) bc[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0 && counts) counts[blockIdx.x] = carry;
+}
+
+template <typename Pred>
+__global__ void __launch_bounds__(256) ccl_assign_kernel(const int *__restrict__ parent, const int *__restrict__ blockoff,
+                                                          int *__restrict__ labels, Pred pred, int64_t n, int nblk)
+{
+    const int b = blockIdx.y;
+    const int *par = parent + (int64_t)b * n;
+    int64_t i0 = (int64_t)blockIdx.x * SCAN_PIX + threadIdx.x * 4;
+    bool isroot[4];
+    int cnt = 0;
+    for (int j = 0; j < 4; ++j) {
+        int64_t i = i0 + j;
+        isroot[j] = i < n && par[i] == (int)i && pred((int64_t)b * n + i);
+        cnt += isroot[j];
+    }
+    int total;
+    int ex = block_exclusive_scan(cnt, &total);
+    int next = blockoff[b * nblk + blockIdx.x] + ex;
+    for (int j = 0; j < 4; ++j)
+        if (isroot[j]) labels[(int64_t)b * n + i0 + j] = ++next;
+}
+
+template <typename Pred>
+__global__ void __launch_bounds__(256) ccl_relabel_kernel(const int *__restrict__ parent, int *__restrict__ labels,
+                                                           Pred pred, int64_t n)
+{
+    const int b = blockIdx.y;
+    const int *par = parent + (int64_t)b * n;
+    int *lab = labels + (int64_t)b * n;
+    int64_t i0 = (int64_t)blockIdx.x * SCAN_PIX + threadIdx.x * 4;
+    for (int j = 0; j < 4; ++j) {
+        int64_t i = i0 + j;
+        if (i >= n) break;
+        int p = par[i];
+        if (p == (int)i && pred((int64_t)b * n + i)) continue;  // accepted roots were written by the assign pass
+        lab[i] = (p >= 0 && pred((int64_t)b * n + p)) ? lab[p] : 0;
+    }
+}
+
+// ---- host-side drivers ---------------------------------------------------
+struct CclWs {
+    int *parent;
+    int *blockcount;
+    int nblk;
+};
+
+static size_t ccl_ws_bytes(int B, int H, int W)
+{
+    int64_t n = (int64_t)H * W;
+    int nblk = (int)((n + SCAN_PIX - 1) / SCAN_PIX);
+    return align_up(sizeof(int) * (size_t)B * n) + align_up(sizeof(int) * (size_t)B * nblk);
+}
+
+static CclWs ccl_carve(Carver &cv, int B, int H, int W)
+{
+    int64_t n = (int64_t)H * W;
+    CclWs ws;
+    ws.nblk = (int)((n + SCAN_PIX - 1) / SCAN_PIX);
+    ws.parent = cv.take<int>((size_t)B * n);
+    ws.blockcount = cv.take<int>((size_t)B * ws.nblk);
+    return ws;
+}
+
+template <typename KeyFn, bool CONN8>
+static int ccl_roots(KeyFn keyfn, int *parent, int B, int H, int W, hipStream_t s)
+{
+    dim3 tgrid((W + CCL_TW - 1) / CCL_TW, (H + CCL_TH - 1) / CCL_TH, B);
+    hipLaunchKernelGGL((ccl_tile_kernel<KeyFn, CONN8>), tgrid, dim3(256), 0, s, keyfn, parent, H, W);
+    PCSEG_CHECK_LAUNCH();
+    if (tgrid.x > 1 || tgrid.y > 1) {
+        dim3 bgrid((W + 63) / 64, (H + 3) / 4, B);
+        hipLaunchKernelGGL((ccl_border_kernel<KeyFn, CONN8>), bgrid, dim3(256), 0, s, keyfn, parent, H, W);
+        PCSEG_CHECK_LAUNCH();
+    }
+    return PCSEG_OK;
+}
+
+// parent must hold roots that are NOT yet flattened when flatten == true
+template <typename Pred>
+static int ccl_compact(int *parent, int *blockcount, int nblk, int *labels, int *counts, Pred pred, bool flatten,
+                       int B, int H, int W, hipStream_t s)
+{
+    int64_t n = (int64_t)H * W;
+    dim3 grid(nblk, B);
+    hipLaunchKernelGGL((ccl_flatten_count_kernel<Pred>), grid, dim3(256), 0, s, parent, blockcount, pred, n, nblk, flatten);
+    PCSEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, blockcount, counts, nblk);
+    PCSEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL((ccl_assign_kernel<Pred>), grid, dim3(256), 0, s, parent, blockcount, labels, pred, n, nblk);
+    PCSEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL((ccl_relabel_kernel<Pred>), grid, dim3(256), 0, s, parent, labels, pred, n);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+template <typename KeyFn, bool CONN8>
+static int ccl_full(KeyFn keyfn, int32_t *labels, int32_t *counts, int B, int H, int W, void *workspace,
+                    size_t workspace_bytes, hipStream_t s)
+{
+    Carver cv(workspace, workspace_bytes);
+    CclWs ws = ccl_carve(cv, B, H, W);
+    if (!cv.ok()) {
+        set_error("ccl: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    int rc = ccl_roots<KeyFn, CONN8>(keyfn, ws.parent, B, H, W, s);
+    if (rc) return rc;
+    return ccl_compact(ws.parent, ws.blockcount, ws.nblk, labels, counts, PredAll(), true, B, H, W, s);
+}
+
+// ---- roots(+1) image -> parent(-1 bg) conversion for pcseg_compact_labels
+__global__ void __launch_bounds__(256) roots_to_parent_kernel(const int *__restrict__ roots, int *__restrict__ parent, int64_t total)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) parent[i] = roots[i] - 1;
+}
+
+// ---- fill holes ------------------------------------------------------------
+__global__ void __launch_bounds__(256) border_flag_kernel(const int *__restrict__ parent, uint8_t *__restrict__ flag, int H, int W)
+{
+    // one thread per border pixel: t in [0, 2W + 2H)
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int r, c;
+    if (t < W) { r = 0; c = t; }
+    else if (t < 2 * W) { r = H - 1; c = t - W; }
+    else if (t < 2 * W + H) { r = t - 2 * W; c = 0; }
+    else if (t < 2 * W + 2 * H) { r = t - 2 * W - H; c = W - 1; }
+    else return;
+    int64_t fbase = (int64_t)blockIdx.y * H * W;
+    int p = parent[fbase + (int64_t)r * W + c];
+    if (p >= 0) flag[fbase + p] = 1;
+}
+
+__global__ void __launch_bounds__(256) fill_holes_out_kernel(const uint8_t *__restrict__ mask, const int *__restrict__ parent,
+                                                              const uint8_t *__restrict__ flag, uint8_t *__restrict__ out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t fbase = (int64_t)blockIdx.y * n;
+    int p = parent[fbase + i];
+    out[fbase + i] = (mask[fbase + i] != 0) || (p >= 0 && flag[fbase + p] == 0);
+}
+
+// plain flatten (no counting)
+__global__ void __launch_bounds__(256) ccl_flatten_kernel(int *__restrict__ parent, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int *par = parent + (int64_t)blockIdx.y * n;
+    int p = par[i];
+    if (p < 0) return;
+    int x = p, q;
+    while ((q = par[x]) != x) x = q;
+    if (x != p) par[i] = x;
+}
+
+// ---- local maxima ----------------------------------------------------------
+// candidate: no strictly higher 8-neighbour.  key = candidate ? value-rank key : 0.
+__global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__restrict__ img, int *__restrict__ key,
+                                                                 int *__restrict__ nonconst, int H, int W)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= H || c >= W) return;
+    const int64_t fbase = (int64_t)blockIdx.z * H * W;
+    const int *im = img + fbase;
+    const int v = im[(int64_t)r * W + c];
+    bool cand = true, differs = false;
+    for (int dr = -1; dr <= 1; ++dr)
+        for (int dc = -1; dc <= 1; ++dc) {
+            int rr = r + dr, cc = c + dc;
+            if ((dr == 0 && dc == 0) || rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+            int q = im[(int64_t)rr * W + cc];
+            cand = cand && (q <= v);
+            differs = differs || (q != v);
+        }
+    // key must be non-zero for candidates and equal exactly when the values are equal:
+    // values are >= INT_MIN; map v -> (v ^ 0x80000000) + 1 would overflow for INT_MAX only.
+    key[fbase + (int64_t)r * W + c] = cand ? (v == 0 ? (int)0x80000000 : v) : 0;
+    if (differs && nonconst[blockIdx.z] == 0) nonconst[blockIdx.z] = 1;
+}
+
+// bad[root] = 1 if any candidate of the component touches an equal-valued non-candidate
+__global__ void __launch_bounds__(256) locmax_bad_kernel(const int *__restrict__ img, const int *__restrict__ key,
+                                                          const int *__restrict__ parent, uint8_t *__restrict__ bad, int H, int W)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= H || c >= W) return;
+    const int64_t fbase = (int64_t)blockIdx.z * H * W;
+    const int p = r * W + c;
+    if (key[fbase + p] == 0) return;
+    const int v = img[fbase + p];
+    bool touches = false;
+    for (int dr = -1; dr <= 1; ++dr)
+        for (int dc = -1; dc <= 1; ++dc) {
+            int rr = r + dr, cc = c + dc;
+            if ((dr == 0 && dc == 0) || rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+            int64_t q = fbase + (int64_t)rr * W + cc;
+            touches = touches || (img[q] == v && key[q] == 0);
+        }
+    if (touches) bad[fbase + parent[fbase + p]] = 1;
+}
+
+__global__ void __launch_bounds__(256) locmax_out_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ bad,
+                                                          const int *__restrict__ nonconst, uint8_t *__restrict__ is_max, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t fbase = (int64_t)blockIdx.y * n;
+    int p = parent[fbase + i];
+    is_max[fbase + i] = (p >= 0 && bad[fbase + p] == 0 && nonconst[blockIdx.y] != 0);
+}
+
+// a constant frame has no maxima: flag every pixel bad so that compaction counts nothing
+__global__ void __launch_bounds__(256) locmax_const_kernel(uint8_t *__restrict__ bad, const int *__restrict__ nonconst, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || nonconst[blockIdx.y] != 0) return;
+    bad[(int64_t)blockIdx.y * n + i] = 1;
+}
+
+// ---- overlap removal (C6) --------------------------------------------------
+__global__ void __launch_bounds__(256) overlap_count_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ other,
+                                                             int *__restrict__ area, int *__restrict__ ov, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t fbase = (int64_t)blockIdx.y * n;
+    int p = parent[fbase + i];
+    if (p < 0) return;
+    atomicAdd(&area[fbase + p], 1);
+    if (other[fbase + i] == 1) atomicAdd(&ov[fbase + p], 1);
+}
+
+__global__ void __launch_bounds__(256) overlap_out_kernel(const uint8_t *__restrict__ dapi, const int *__restrict__ parent,
+                                                           const int *__restrict__ area, const int *__restrict__ ov,
+                                                           double threshold, uint8_t *__restrict__ out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t fbase = (int64_t)blockIdx.y * n;
+    int p = parent[fbase + i];
+    uint8_t v = dapi[fbase + i];
+    if (p >= 0) {
+        double frac = (double)ov[fbase + p] / (double)area[fbase + p];
+        if (frac > threshold) v = 2;
+    }
+    out[fbase + i] = v;
+}
+
+}  // namespace pcseg
+
+using namespace pcseg;
+
+extern "C" {
+
+size_t pcseg_ccl_workspace_bytes(int B, int H, int W)
+{
+    if (!check_shape(B, H, W)) return 0;
+    return ccl_ws_bytes(B, H, W);
+}
+
+int pcseg_ccl8_equal_u8(const uint8_t *in, int32_t *labels, int32_t *counts, int B, int H, int W, void *workspace,
+                        size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(in && labels && counts && workspace && check_shape(B, H, W), "bad arguments");
+    return ccl_full<KeyEqU8, true>(KeyEqU8{in}, labels, counts, B, H, W, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pcseg_ccl8_bool(const uint8_t *in, int32_t *labels, int32_t *counts, int B, int H, int W, void *workspace,
+                    size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(in && labels && counts && workspace && check_shape(B, H, W), "bad arguments");
+    return ccl_full<KeyNzU8, true>(KeyNzU8{in}, labels, counts, B, H, W, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pcseg_ccl4_bool(const uint8_t *in, int32_t *labels, int32_t *counts, int B, int H, int W, void *workspace,
+                    size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(in && labels && counts && workspace && check_shape(B, H, W), "bad arguments");
+    return ccl_full<KeyNzU8, false>(KeyNzU8{in}, labels, counts, B, H, W, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pcseg_compact_labels(const int32_t *roots, int32_t *labels, int32_t *counts, int B, int H, int W, void *workspace,
+                         size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(roots && labels && counts && workspace && roots != labels && check_shape(B, H, W), "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    CclWs ws = ccl_carve(cv, B, H, W);
+    if (!cv.ok()) {
+        set_error("compact_labels: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    int64_t total = (int64_t)B * H * W;
+    hipLaunchKernelGGL(roots_to_parent_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, roots, ws.parent, total);
+    PCSEG_CHECK_LAUNCH();
+    return ccl_compact(ws.parent, ws.blockcount, ws.nblk, labels, counts, PredAll(), true, B, H, W, s);
+}
+
+size_t pcseg_fill_holes_workspace_bytes(int B, int H, int W)
+{
+    if (!check_shape(B, H, W)) return 0;
+    return ccl_ws_bytes(B, H, W) + align_up((size_t)B * H * W);
+}
+
+int pcseg_fill_holes(const uint8_t *mask, uint8_t *out, int B, int H, int W, void *workspace, size_t workspace_bytes,
+                     pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(mask && out && workspace && check_shape(B, H, W), "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t n = (int64_t)H * W;
+    Carver cv(workspace, workspace_bytes);
+    CclWs ws = ccl_carve(cv, B, H, W);
+    uint8_t *flag = cv.take<uint8_t>((size_t)B * n);
+    if (!cv.ok()) {
+        set_error("fill_holes: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    int rc = ccl_roots<KeyZeroU8, false>(KeyZeroU8{mask}, ws.parent, B, H, W, s);
+    if (rc) return rc;
+    dim3 g1((unsigned)((n + 255) / 256), B);
+    hipLaunchKernelGGL(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_CHECK_HIP(hipMemsetAsync(flag, 0, (size_t)B * n, s));
+    hipLaunchKernelGGL(border_flag_kernel, dim3((2 * W + 2 * H + 255) / 256, B), dim3(256), 0, s, ws.parent, flag, H, W);
+    PCSEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fill_holes_out_kernel, g1, dim3(256), 0, s, mask, ws.parent, flag, out, n);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+size_t pcseg_local_maxima_workspace_bytes(int B, int H, int W)
+{
+    if (!check_shape(B, H, W)) return 0;
+    size_t n = (size_t)H * W;
+    return ccl_ws_bytes(B, H, W) + align_up(sizeof(int) * B * n) + align_up((size_t)B * n) + align_up(sizeof(int) * B);
+}
+
+int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers, int32_t *counts, int B, int H, int W,
+                           void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(img && workspace && check_shape(B, H, W), "bad arguments");
+    PCSEG_REQUIRE(!markers || counts, "markers need counts");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t n = (int64_t)H * W;
+    Carver cv(workspace, workspace_bytes);
+    CclWs ws = ccl_carve(cv, B, H, W);
+    int *key = cv.take<int>((size_t)B * n);
+    uint8_t *bad = cv.take<uint8_t>((size_t)B * n);
+    int *nonconst = cv.take<int>(B);
+    if (!cv.ok()) {
+        set_error("local_maxima: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    PCSEG_CHECK_HIP(hipMemsetAsync(nonconst, 0, sizeof(int) * B, s));
+    PCSEG_CHECK_HIP(hipMemsetAsync(bad, 0, (size_t)B * n, s));
+    dim3 g2((W + 63) / 64, (H + 3) / 4, B);
+    hipLaunchKernelGGL(locmax_candidates_kernel, g2, dim3(256), 0, s, img, key, nonconst, H, W);
+    PCSEG_CHECK_LAUNCH();
+    int rc = ccl_roots<KeyI32, true>(KeyI32{key}, ws.parent, B, H, W, s);
+    if (rc) return rc;
+    dim3 g1((unsigned)((n + 255) / 256), B);
+    hipLaunchKernelGGL(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);
+    PCSEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(locmax_bad_kernel, g2, dim3(256), 0, s, img, key, ws.parent, bad, H, W);
+    PCSEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(locmax_const_kernel, g1, dim3(256), 0, s, bad, nonconst, n);
+    PCSEG_CHECK_LAUNCH();
+    if (is_max) {
+        hipLaunchKernelGGL(locmax_out_kernel, g1, dim3(256), 0, s, ws.parent, bad, nonconst, is_max, n);
+        PCSEG_CHECK_LAUNCH();
+    }
+    if (markers) {
+        rc = ccl_compact(ws.parent, ws.blockcount, ws.nblk, markers, counts, PredNotFlagged{bad}, false, B, H, W, s);
+        if (rc) return rc;
+    }
+    return PCSEG_OK;
+}
+
+size_t pcseg_overlap_workspace_bytes(int B, int H, int W)
+{
+    if (!check_shape(B, H, W)) return 0;
+    size_t n = (size_t)H * W;
+    return ccl_ws_bytes(B, H, W) + 2 * align_up(sizeof(int) * B * n);
+}
+
+int pcseg_remove_overlapping(const uint8_t *dapi, const uint8_t *other, double threshold, uint8_t *out, int B, int H, int W,
+                             void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(dapi && other && out && workspace && check_shape(B, H, W), "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t n = (int64_t)H * W;
+    Carver cv(workspace, workspace_bytes);
+    CclWs ws = ccl_carve(cv, B, H, W);
+    int *area = cv.take<int>((size_t)B * n);
+    int *ov = cv.take<int>((size_t)B * n);
+    if (!cv.ok()) {
+        set_error("remove_overlapping: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    int rc = ccl_roots<KeyIsOneU8, true>(KeyIsOneU8{dapi}, ws.parent, B, H, W, s);
+    if (rc) return rc;
+    dim3 g1((unsigned)((n + 255) / 256), B);
+    hipLaunchKernelGGL(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_CHECK_HIP(hipMemsetAsync(area, 0, sizeof(int) * (size_t)B * n, s));
+    PCSEG_CHECK_HIP(hipMemsetAsync(ov, 0, sizeof(int) * (size_t)B * n, s));
+    hipLaunchKernelGGL(overlap_count_kernel, g1, dim3(256), 0, s, ws.parent, other, area, ov, n);
+    PCSEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(overlap_out_kernel, g1, dim3(256), 0, s, dapi, ws.parent, area, ov, threshold, out, n);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// Shared helpers of libpcseg (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pcseg.h"
+
+namespace pcseg {
+
+constexpr int WAVE = 64;
+
+void set_error(const char *fmt, ...);
+
+#define PCSEG_CHECK_HIP(expr)                                                              \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            pcseg::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PCSEG_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+#define PCSEG_CHECK_LAUNCH()                                                               \
+    do {                                                                                   \
+        hipError_t _e = hipGetLastError();                                                 \
+        if (_e != hipSuccess) {                                                            \
+            pcseg::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PCSEG_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+#define PCSEG_REQUIRE(cond, msg)                                                           \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            pcseg::set_error("%s: %s", __func__, msg);                                     \
+            return PCSEG_ERR_ARG;                                                          \
+        }                                                                                  \
+    } while (0)
+
+inline int check_shape(int B, int H, int W)
+{
+    // linear indices are int32 per frame; rows/cols are stored as uint16 in the EDT scratch
+    if (B < 1 || H < 1 || W < 1) return 0;
+    if ((int64_t)H * W >= ((int64_t)1 << 30)) return 0;
+    if (H > 32768 || W > 32768) return 0;
+    return 1;
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// carve typed regions out of the caller's workspace
+struct Carver {
+    char *base;
+    size_t off = 0;
+    size_t cap;
+    Carver(void *p, size_t bytes) : base((char *)p), cap(bytes) {}
+    template <typename T>
+    T *take(size_t n)
+    {
+        size_t bytes = align_up(n * sizeof(T));
+        T *p = (T *)(base + off);
+        off += bytes;
+        return p;
+    }
+    bool ok() const { return off <= cap && base != nullptr; }
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// relaxed agent-scope accesses: served by L2, never by a stale L1 line
+__device__ __forceinline__ int ld_agent(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace pcseg

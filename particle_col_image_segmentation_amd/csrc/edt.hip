@@ -1,0 +1,309 @@
+// Exact squared Euclidean distance transform (R2) and the operators that are
+// thresholds of it: disk(r) dilation (A6) and fill_particle_area (A8).
+//
+// Separable, integers only.  The input is read ONCE and reduced to one bit per
+// pixel (32-row column words); vertical distances come from bit scans of those
+// words plus a per-column carry across words, are staged per 8-row block in LDS
+// as uint16, and the horizontal pass is an expanding search that stops as soon
+// as k*k >= best (exact: the candidate at offset k is >= k*k).  HBM traffic is
+// the input read plus the int32 (or uint8) result write.
+#include "common.h"
+
+namespace pcseg {
+
+constexpr int EDT_CH = 32;          // rows per bit word
+constexpr int EDT_RB = 8;           // rows per horizontal-pass block
+constexpr unsigned G_INF = 0xFFFFu;  // "no zero pixel in this column"
+
+// ---- foreground predicates (distance is measured TO the nearest non-foreground pixel)
+struct FgNzU8 {
+    const uint8_t *p;
+    __device__ __forceinline__ bool operator()(int64_t i) const { return p[i] != 0; }
+};
+struct FgLtF32 {
+    const float *p;
+    float thr;
+    uint8_t *mask_out;
+    __device__ __forceinline__ bool operator()(int64_t i) const
+    {
+        bool m = p[i] < thr;
+        if (mask_out) mask_out[i] = m;
+        return m;
+    }
+};
+struct FgNotInSetU8 {
+    const uint8_t *p;
+    unsigned long long bits;
+    __device__ __forceinline__ bool operator()(int64_t i) const
+    {
+        unsigned v = p[i];
+        return !(v < 64 && ((bits >> v) & 1ull));
+    }
+};
+
+// one thread per (word, column): fg bits of 32 rows; any_bg[b] |= (some pixel is not fg)
+template <typename Fg>
+__global__ void __launch_bounds__(256) edt_bits_kernel(Fg fg, unsigned *__restrict__ bits, int *__restrict__ any_bg, int H, int W, int nch)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    if (c >= W) return;
+    const int64_t fbase = (int64_t)b * H * W;
+    const int r0 = ch * EDT_CH;
+    unsigned word = 0, valid = 0;
+#pragma unroll 8
+    for (int j = 0; j < EDT_CH; ++j) {
+        int r = r0 + j;
+        if (r < H) {
+            valid |= 1u << j;
+            if (fg(fbase + (int64_t)r * W + c)) word |= 1u << j;
+        }
+    }
+    bits[((int64_t)b * nch + ch) * W + c] = word;
+    if ((word & valid) != valid && any_bg[b] == 0) any_bg[b] = 1;
+}
+
+// per column: distance from the first row of each word to the nearest zero above it (up),
+// and from the last row of each word to the nearest zero below it (dn); G_INF if none.
+__global__ void __launch_bounds__(256) edt_carry_kernel(const unsigned *__restrict__ bits, uint16_t *__restrict__ up,
+                                                         uint16_t *__restrict__ dn, int H, int W, int nch)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (c >= W) return;
+    const int64_t base = (int64_t)b * nch * W + c;
+    unsigned d = G_INF;  // distance from row (r0 - 1) ... tracked as "distance of first row of the word to the zero"
+    for (int ch = 0; ch < nch; ++ch) {
+        up[base + (int64_t)ch * W] = (uint16_t)d;
+        int rows = min(EDT_CH, H - ch * EDT_CH);
+        unsigned valid = rows == 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
+        unsigned zero = ~bits[base + (int64_t)ch * W] & valid;
+        if (zero) d = rows - (31 - __clz(zero));  // from first row of next word to the last zero of this word
+        else d = d == G_INF ? G_INF : d + rows;
+    }
+    d = G_INF;
+    for (int ch = nch - 1; ch >= 0; --ch) {
+        dn[base + (int64_t)ch * W] = (uint16_t)d;
+        int rows = min(EDT_CH, H - ch * EDT_CH);
+        unsigned valid = rows == 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
+        unsigned zero = ~bits[base + (int64_t)ch * W] & valid;
+        if (zero) d = (__ffs(zero) - 1) + 1;  // from last row of previous word to the first zero of this word
+        else d = d == G_INF ? G_INF : d + rows;
+    }
+}
+
+// vertical distance of row j (0..31) of a word
+__device__ __forceinline__ unsigned vdist(unsigned word, unsigned valid, int j, unsigned up, unsigned dn, int rows)
+{
+    if (!((word >> j) & 1u)) return 0;
+    unsigned zero = ~word & valid;
+    unsigned below_or_at = zero & (j == 31 ? 0xFFFFFFFFu : ((2u << j) - 1u));  // zeros in rows <= j
+    unsigned above = zero & ~(j == 31 ? 0xFFFFFFFFu : ((2u << j) - 1u));        // zeros in rows > j
+    unsigned d1 = below_or_at ? (unsigned)(j - (31 - __clz(below_or_at))) : (up == G_INF ? G_INF : up + j);
+    unsigned d2 = above ? (unsigned)((__ffs(above) - 1) - j) : (dn == G_INF ? G_INF : dn + (rows - 1 - j));
+    return min(min(d1, d2), G_INF);
+}
+
+// ---- epilogues of the horizontal pass
+struct EpiD2 {
+    int *d2;
+    int cap;  // < 0: exact
+    __device__ __forceinline__ int kmax(int W) const { return cap < 0 ? W : (int)sqrtf((float)cap) + 1; }
+    __device__ __forceinline__ bool wants(int64_t) const { return true; }
+    __device__ __forceinline__ void store(int64_t i, long long v, bool any_bg, int r, int c, unsigned long long &cnt) const
+    {
+        if (!any_bg) v = (long long)(r + 1) * (r + 1) + (long long)c * c;  // scipy: virtual zero pixel at (-1, 0)
+        if (cap >= 0 && v > cap) v = (long long)cap + 1;
+        d2[i] = (int)v;
+    }
+};
+struct EpiDilate {
+    uint8_t *out;
+    int r2;
+    __device__ __forceinline__ int kmax(int) const { return (int)sqrtf((float)r2) + 1; }
+    __device__ __forceinline__ bool wants(int64_t) const { return true; }
+    __device__ __forceinline__ void store(int64_t i, long long v, bool any_bg, int, int, unsigned long long &) const
+    {
+        out[i] = (any_bg && v <= r2) ? 1 : 0;  // empty set dilates to the empty set
+    }
+};
+struct EpiFillParticle {
+    const uint8_t *ds;
+    uint8_t *out;
+    int cell_label, overlap_label, r2, thr2;  // overlap if d2 <= r2 (dilation) or d2 < thr2 (distance)
+    __device__ __forceinline__ int kmax(int) const { return (int)sqrtf((float)max(r2, thr2)) + 1; }
+    __device__ __forceinline__ bool wants(int64_t i) const { return ds[i] == cell_label; }
+    __device__ __forceinline__ void store(int64_t i, long long v, bool any_bg, int r, int c, unsigned long long &cnt) const
+    {
+        uint8_t z = ds[i];
+        if (z == cell_label) {
+            bool ov;
+            if (any_bg) ov = (v <= r2) || (v < thr2);
+            else ov = ((long long)(r + 1) * (r + 1) + (long long)c * c) < thr2;  // only the EDT term sees the virtual pixel
+            if (ov) { z = (uint8_t)overlap_label; ++cnt; }
+        }
+        out[i] = z;
+    }
+};
+
+template <typename Epi>
+__global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict__ bits, const uint16_t *__restrict__ up,
+                                                       const uint16_t *__restrict__ dn, const int *__restrict__ any_bg,
+                                                       Epi epi, unsigned long long *__restrict__ count, int H, int W, int nch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t g[];  // [EDT_RB][W]
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * EDT_RB;
+    const int ch = r0 / EDT_CH, j0 = r0 % EDT_CH;
+    const int rows_in_word = min(EDT_CH, H - ch * EDT_CH);
+    const unsigned valid = rows_in_word == 32 ? 0xFFFFFFFFu : ((1u << rows_in_word) - 1u);
+    const int nrows = min(EDT_RB, H - r0);
+    const int64_t wbase = ((int64_t)b * nch + ch) * W;
+    for (int c = threadIdx.x; c < W; c += 256) {
+        unsigned word = bits[wbase + c];
+        unsigned u = up[wbase + c], d = dn[wbase + c];
+#pragma unroll
+        for (int j = 0; j < EDT_RB; ++j)
+            if (j < nrows) g[j * W + c] = (uint16_t)vdist(word, valid, j0 + j, u, d, rows_in_word);
+    }
+    __syncthreads();
+    const bool anybg = any_bg[b] != 0;
+    const int kmax = epi.kmax(W);
+    const int64_t fbase = (int64_t)b * H * W;
+    unsigned long long cnt = 0;
+    for (int idx = threadIdx.x; idx < nrows * W; idx += 256) {
+        const int j = idx / W, c = idx % W;
+        const int64_t gi = fbase + (int64_t)(r0 + j) * W + c;
+        const uint16_t *gr = g + j * W;
+        long long best;
+        if (!epi.wants(gi)) {
+            best = 0;
+        } else {
+            unsigned g0 = gr[c];
+            best = g0 == G_INF ? (1ll << 40) : (long long)g0 * g0;
+            for (int k = 1; k <= kmax && (long long)k * k < best; ++k) {
+                long long kk = (long long)k * k;
+                if (c - k >= 0) {
+                    unsigned gl = gr[c - k];
+                    if (gl != G_INF) best = min(best, (long long)gl * gl + kk);
+                }
+                if (c + k < W) {
+                    unsigned gq = gr[c + k];
+                    if (gq != G_INF) best = min(best, (long long)gq * gq + kk);
+                }
+                if (c - k < 0 && c + k >= W) break;
+            }
+        }
+        epi.store(gi, best, anybg, r0 + j, c, cnt);
+    }
+    if (count) {
+        for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (lane_id() == 0 && cnt) atomicAdd(&count[b], cnt);
+    }
+}
+
+struct EdtWs {
+    unsigned *bits;
+    uint16_t *up, *dn;
+    int *any_bg;
+    int nch;
+};
+
+static size_t edt_ws_bytes(int B, int H, int W)
+{
+    int nch = (H + EDT_CH - 1) / EDT_CH;
+    size_t words = (size_t)B * nch * W;
+    return align_up(words * 4) + 2 * align_up(words * 2) + align_up(sizeof(int) * B);
+}
+
+static EdtWs edt_carve(Carver &cv, int B, int H, int W)
+{
+    EdtWs ws;
+    ws.nch = (H + EDT_CH - 1) / EDT_CH;
+    size_t words = (size_t)B * ws.nch * W;
+    ws.bits = cv.take<unsigned>(words);
+    ws.up = cv.take<uint16_t>(words);
+    ws.dn = cv.take<uint16_t>(words);
+    ws.any_bg = cv.take<int>(B);
+    return ws;
+}
+
+template <typename Fg, typename Epi>
+static int edt_run(Fg fg, Epi epi, unsigned long long *count, int B, int H, int W, void *workspace, size_t workspace_bytes,
+                   hipStream_t s, const char *who)
+{
+    Carver cv(workspace, workspace_bytes);
+    EdtWs ws = edt_carve(cv, B, H, W);
+    if (!cv.ok()) {
+        set_error("%s: workspace too small (%zu < %zu)", who, workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    size_t lds = (size_t)EDT_RB * W * sizeof(uint16_t);
+    if (lds > 160 * 1024) {
+        set_error("%s: W = %d too wide for the LDS row stage", who, W);
+        return PCSEG_ERR_ARG;
+    }
+    PCSEG_CHECK_HIP(hipMemsetAsync(ws.any_bg, 0, sizeof(int) * B, s));
+    dim3 g1((W + 255) / 256, ws.nch, B);
+    hipLaunchKernelGGL((edt_bits_kernel<Fg>), g1, dim3(256), 0, s, fg, ws.bits, ws.any_bg, H, W, ws.nch);
+    PCSEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(edt_carry_kernel, dim3((W + 255) / 256, B), dim3(256), 0, s, ws.bits, ws.up, ws.dn, H, W, ws.nch);
+    PCSEG_CHECK_LAUNCH();
+    if (lds > 64 * 1024)
+        PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)edt_row_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 g2((H + EDT_RB - 1) / EDT_RB, B);
+    hipLaunchKernelGGL((edt_row_kernel<Epi>), g2, dim3(256), lds, s, ws.bits, ws.up, ws.dn, ws.any_bg, epi, count, H, W, ws.nch);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+}  // namespace pcseg
+
+using namespace pcseg;
+
+extern "C" {
+
+size_t pcseg_edt_workspace_bytes(int B, int H, int W)
+{
+    if (!check_shape(B, H, W)) return 0;
+    return edt_ws_bytes(B, H, W);
+}
+
+int pcseg_edt_sq_u8(const uint8_t *mask, int32_t *d2, int B, int H, int W, int cap, void *workspace, size_t workspace_bytes,
+                    pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(mask && d2 && workspace && check_shape(B, H, W), "bad arguments");
+    return edt_run(FgNzU8{mask}, EpiD2{d2, cap}, nullptr, B, H, W, workspace, workspace_bytes, (hipStream_t)stream, "edt_sq_u8");
+}
+
+int pcseg_edt_sq_lt_f32(const float *img, float threshold, int32_t *d2, uint8_t *mask_out, int B, int H, int W,
+                        void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(img && d2 && workspace && check_shape(B, H, W), "bad arguments");
+    return edt_run(FgLtF32{img, threshold, mask_out}, EpiD2{d2, -1}, nullptr, B, H, W, workspace, workspace_bytes,
+                   (hipStream_t)stream, "edt_sq_lt_f32");
+}
+
+int pcseg_dilate_disk_u8(const uint8_t *in, uint64_t value_bits, int radius, uint8_t *out, int B, int H, int W,
+                         void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(in && out && in != out && workspace && radius >= 0 && radius <= 180 && check_shape(B, H, W), "bad arguments");
+    return edt_run(FgNotInSetU8{in, value_bits}, EpiDilate{out, radius * radius}, nullptr, B, H, W, workspace, workspace_bytes,
+                   (hipStream_t)stream, "dilate_disk_u8");
+}
+
+int pcseg_fill_particle(const uint8_t *ds, uint8_t *out, int particle_label, int cell_label, int overlap_label,
+                        int dilation_radius, int dist_threshold, int64_t *overlap_area, int B, int H, int W, void *workspace,
+                        size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(ds && out && ds != out && workspace && check_shape(B, H, W), "bad arguments");
+    PCSEG_REQUIRE(particle_label >= 0 && particle_label < 64 && cell_label >= 0 && cell_label < 256 && overlap_label >= 0 &&
+                      overlap_label < 256 && dilation_radius >= 0 && dilation_radius <= 180 && dist_threshold >= 0 &&
+                      dist_threshold <= 180,
+                  "labels / radii out of range");
+    EpiFillParticle epi{ds, out, cell_label, overlap_label, dilation_radius * dilation_radius, dist_threshold * dist_threshold};
+    return edt_run(FgNotInSetU8{ds, 1ull << particle_label}, epi, (unsigned long long *)overlap_area, B, H, W, workspace,
+                   workspace_bytes, (hipStream_t)stream, "fill_particle");
+}
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+// Pointwise and small-stencil kernels: class-map ingest (argmax), 5x5 median
+// (A1), threshold (R1), 3x3 morphology (X2), Otsu histogram (X1).
+// HBM-bound byte work: coalesced row-major loads, LDS tile with halo for the
+// median, no MFMA (nothing here is a contraction).
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace pcseg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------- argmax
+// 4 pixels per thread when the plane size allows 16-byte loads.
+template <bool VEC>
+__global__ void __launch_bounds__(256) argmax_kernel(const float *__restrict__ stack, uint8_t *__restrict__ cls,
+                                                      int C, int64_t n /* H*W */)
+{
+    const int b = blockIdx.y;
+    const float *fr = stack + (int64_t)b * C * n;
+    uint8_t *out = cls + (int64_t)b * n;
+    if (VEC) {
+        int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i4 * 4 >= n) return;
+        float4 best = *reinterpret_cast<const float4 *>(fr + i4 * 4);
+        uchar4 arg = make_uchar4(1, 1, 1, 1);
+        for (int k = 1; k < C; ++k) {
+            float4 v = *reinterpret_cast<const float4 *>(fr + k * n + i4 * 4);
+            if (v.x > best.x) { best.x = v.x; arg.x = k + 1; }
+            if (v.y > best.y) { best.y = v.y; arg.y = k + 1; }
+            if (v.z > best.z) { best.z = v.z; arg.z = k + 1; }
+            if (v.w > best.w) { best.w = v.w; arg.w = k + 1; }
+        }
+        *reinterpret_cast<uchar4 *>(out + i4 * 4) = arg;
+    } else {
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= n) return;
+        float best = fr[i];
+        int arg = 1;
+        for (int k = 1; k < C; ++k) {
+            float v = fr[k * n + i];
+            if (v > best) { best = v; arg = k + 1; }
+        }
+        out[i] = (uint8_t)arg;
+    }
+}
+
+// ---------------------------------------------------------------- median
+// Tile 64x32 outputs per 256-thread block, 2-pixel reflected halo, each thread
+// produces a 4-pixel horizontal strip for 2 rows.  The median of the 25 window
+// bytes is built bit by bit: med = max t with #(v >= t) >= 13; the number of
+// bit rounds is block-uniform (from the tile maximum), so a class map with
+// values <= 7 costs 3 rounds.
+constexpr int MED_TW = 64, MED_TH = 32, MED_LW = 72 /* 64 + 4 rounded to 8 */, MED_LH = MED_TH + 4;
+
+__device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    int p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - 1 - i;
+}
+
+__global__ void __launch_bounds__(256) median5_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int H, int W)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[MED_LH * MED_LW];
+    __shared__ int tile_max;
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * MED_TH, c0 = blockIdx.x * MED_TW;
+    const uint8_t *src = in + (int64_t)b * H * W;
+    uint8_t *dst = out + (int64_t)b * H * W;
+    if (threadIdx.x == 0) tile_max = 0;
+    __syncthreads();
+    int local_max = 0;
+    for (int i = threadIdx.x; i < MED_LH * (MED_TW + 4); i += 256) {
+        int lr = i / (MED_TW + 4), lc = i % (MED_TW + 4);
+        int rr = reflect_idx(r0 + lr - 2, H), cc = reflect_idx(c0 + lc - 2, W);
+        uint8_t v = src[(int64_t)rr * W + cc];
+        tile[lr * MED_LW + lc] = v;
+        local_max = max(local_max, (int)v);
+    }
+    for (int off = 32; off; off >>= 1) local_max = max(local_max, __shfl_xor(local_max, off));
+    if (lane_id() == 0) atomicMax(&tile_max, local_max);
+    __syncthreads();
+    const int nbits = 32 - __clz(tile_max | 1);
+    // strip id: 16 strips per row, 32 rows -> 512 strips, 2 per thread
+    for (int s = threadIdx.x; s < (MED_TW / 4) * MED_TH; s += 256) {
+        int lr = s / (MED_TW / 4), lc = (s % (MED_TW / 4)) * 4;
+        int r = r0 + lr;
+        if (r >= H || c0 + lc >= W) continue;
+        uint32_t v[5][8];
+#pragma unroll
+        for (int dr = 0; dr < 5; ++dr) {
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(tile + (lr + dr) * MED_LW + lc);
+            uint32_t w0 = row[0], w1 = row[1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[dr][k] = (w0 >> (8 * k)) & 0xFF;
+                v[dr][4 + k] = (w1 >> (8 * k)) & 0xFF;
+            }
+        }
+        uint32_t med[4] = {0, 0, 0, 0};
+        for (int bit = nbits - 1; bit >= 0; --bit) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t t = med[j] | (1u << bit);
+                int cnt = 0;
+#pragma unroll
+                for (int dr = 0; dr < 5; ++dr)
+#pragma unroll
+                    for (int dc = 0; dc < 5; ++dc) cnt += (v[dr][j + dc] >= t) ? 1 : 0;
+                if (cnt >= 13) med[j] = t;
+            }
+        }
+        int c = c0 + lc;
+        if (c + 3 < W && (W & 3) == 0) {
+            *reinterpret_cast<uint32_t *>(dst + (int64_t)r * W + c) =
+                med[0] | (med[1] << 8) | (med[2] << 16) | (med[3] << 24);
+        } else {
+            for (int j = 0; j < 4 && c + j < W; ++j) dst[(int64_t)r * W + c + j] = (uint8_t)med[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- threshold
+__global__ void __launch_bounds__(256) threshold_lt_kernel(const float *__restrict__ img, float thr,
+                                                            uint8_t *__restrict__ mask, int64_t total)
+{
+    int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 + 3 < total && (total & 3) == 0) {
+        float4 v = *reinterpret_cast<const float4 *>(img + i4);
+        *reinterpret_cast<uchar4 *>(mask + i4) = make_uchar4(v.x < thr, v.y < thr, v.z < thr, v.w < thr);
+    } else {
+        for (int j = 0; j < 4 && i4 + j < total; ++j) mask[i4 + j] = img[i4 + j] < thr;
+    }
+}
+
+// ---------------------------------------------------------------- 3x3 morphology
+__global__ void __launch_bounds__(256) morph3x3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                        int erode, int H, int W)
+{
+    int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= H || c >= W) return;
+    const uint8_t *src = in + (int64_t)blockIdx.z * H * W;
+    int acc = erode ? 1 : 0;
+    for (int dr = -1; dr <= 1; ++dr)
+        for (int dc = -1; dc <= 1; ++dc) {
+            int rr = r + dr, cc = c + dc;
+            int v = (rr < 0 || rr >= H || cc < 0 || cc >= W) ? (erode ? 1 : 0) : (src[(int64_t)rr * W + cc] != 0);
+            acc = erode ? (acc & v) : (acc | v);
+        }
+    out[(int64_t)blockIdx.z * H * W + (int64_t)r * W + c] = (uint8_t)acc;
+}
+
+// ---------------------------------------------------------------- Otsu histogram
+__device__ __forceinline__ unsigned f32_ordered(float f)
+{
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_f32(unsigned k)
+{
+    unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+
+__global__ void __launch_bounds__(256) minmax_kernel(const float *__restrict__ img, unsigned *__restrict__ lohi_key, int64_t n)
+{
+    const float *fr = img + (int64_t)blockIdx.y * n;
+    unsigned lo = 0xFFFFFFFFu, hi = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned k = f32_ordered(fr[i]);
+        lo = min(lo, k);
+        hi = max(hi, k);
+    }
+    for (int off = 32; off; off >>= 1) {
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, off));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, off));
+    }
+    if (lane_id() == 0) {
+        atomicMin(&lohi_key[blockIdx.y * 2 + 0], lo);
+        atomicMax(&lohi_key[blockIdx.y * 2 + 1], hi);
+    }
+}
+
+__global__ void keys_to_float_kernel(unsigned *keys, int count)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) keys[i] = __float_as_uint(ordered_f32(keys[i]));
+}
+
+__global__ void __launch_bounds__(256) otsu_hist_kernel(const float *__restrict__ img, const unsigned *__restrict__ lohi_key,
+                                                         unsigned long long *__restrict__ hist, int64_t n)
+{
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const float *fr = img + (int64_t)b * n;
+    const double lo = (double)ordered_f32(lohi_key[b * 2]), hi = (double)ordered_f32(lohi_key[b * 2 + 1]);
+    const double span = hi - lo;
+    const double norm = span > 0 ? 256.0 / span : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double x = (double)fr[i];
+        int bin = 0;
+        if (span > 0) {
+            bin = (int)((x - lo) * norm);
+            if (bin >= 256) bin = 255;
+            double e0 = lo + span * ((double)bin / 256.0), e1 = lo + span * ((double)(bin + 1) / 256.0);
+            if (x < e0 && bin > 0) --bin;
+            else if (x >= e1 && bin < 255) ++bin;
+        }
+        atomicAdd(&h[bin], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[b * 256 + threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+}  // namespace pcseg
+
+using namespace pcseg;
+
+extern "C" {
+
+int pcseg_version(void) { return 100; }
+
+const char *pcseg_last_error(void) { return g_err; }
+
+int pcseg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pcseg_argmax_planes_f32(const float *stack, uint8_t *cls, int B, int C, int H, int W, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(stack && cls && C >= 1 && C <= 255 && check_shape(B, H, W), "bad arguments");
+    int64_t n = (int64_t)H * W;
+    hipStream_t s = (hipStream_t)stream;
+    if ((n & 3) == 0) {
+        dim3 grid((unsigned)((n / 4 + 255) / 256), B);
+        hipLaunchKernelGGL(argmax_kernel<true>, grid, dim3(256), 0, s, stack, cls, C, n);
+    } else {
+        dim3 grid((unsigned)((n + 255) / 256), B);
+        hipLaunchKernelGGL(argmax_kernel<false>, grid, dim3(256), 0, s, stack, cls, C, n);
+    }
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+int pcseg_median5_u8(const uint8_t *in, uint8_t *out, int B, int H, int W, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(in && out && in != out && check_shape(B, H, W), "bad arguments");
+    dim3 grid((W + MED_TW - 1) / MED_TW, (H + MED_TH - 1) / MED_TH, B);
+    hipLaunchKernelGGL(median5_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, H, W);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+int pcseg_threshold_lt_f32(const float *img, float threshold, uint8_t *mask, int B, int H, int W, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(img && mask && check_shape(B, H, W), "bad arguments");
+    int64_t total = (int64_t)B * H * W;
+    unsigned blocks = (unsigned)((total + 1023) / 1024);
+    hipLaunchKernelGGL(threshold_lt_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, threshold, mask, total);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+int pcseg_morph3x3(const uint8_t *mask, uint8_t *out, int erode, int B, int H, int W, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(mask && out && mask != out && check_shape(B, H, W), "bad arguments");
+    dim3 grid((W + 63) / 64, (H + 3) / 4, B);
+    hipLaunchKernelGGL(morph3x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, mask, out, erode, H, W);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+int pcseg_otsu_hist_f32(const float *img, int64_t *hist, float *lohi, int B, int H, int W, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(img && hist && lohi && check_shape(B, H, W), "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t n = (int64_t)H * W;
+    // the float32 lo/hi buffer doubles as the ordered-key scratch of the min/max pass
+    unsigned *keys = reinterpret_cast<unsigned *>(lohi);
+    PCSEG_CHECK_HIP(hipMemsetAsync(hist, 0, sizeof(int64_t) * 256 * B, s));
+    // init lo keys to 0xFFFFFFFF and hi keys to 0: memset pattern per 8 bytes
+    PCSEG_CHECK_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned) * 2 * B, s));
+    for (int b = 0; b < B; ++b) PCSEG_CHECK_HIP(hipMemsetAsync(keys + 2 * b, 0xFF, sizeof(unsigned), s));
+    unsigned gx = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(minmax_kernel, dim3(gx, B), dim3(256), 0, s, img, keys, n);
+    PCSEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(otsu_hist_kernel, dim3(gx, B), dim3(256), 0, s, img, keys, (unsigned long long *)hist, n);
+    PCSEG_CHECK_LAUNCH();
+    // keys -> float32 lo/hi in place, after every histogram block has read them (stream order)
+    hipLaunchKernelGGL(keys_to_float_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, s, keys, 2 * B);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,363 @@
+// Marker-controlled watershed (W1): skimage.segmentation.watershed(image,
+// markers, mask=mask), connectivity 1, no compactness, no watershed line
+// (refine_boundaries.py:73).
+//
+// The reference is a sequential priority flood keyed by (value, age).  Its pop
+// order is ordered first by the minimax ("pass") level
+//     L(seed) = value(seed),  L(q) = max(value(q), min over 4-neighbours L(n)),
+// because every comparison that decides "a pops before b" for L(a) < L(b) is a
+// strict value comparison.  Hence the pixel that labels q (its first-popped
+// neighbour) has L = min over q's neighbours, and
+//   * parallel path: (1) L by tile-iterated relaxation, (2) label propagation
+//     "take the label of a labelled neighbour with L == Lmin", (3) a proof
+//     check: for every non-seed reachable pixel ALL neighbours with L == Lmin
+//     carry the pixel's label.  If the check holds for the whole frame the
+//     result equals the sequential flood's for ANY tie-breaking (induction over
+//     the pop order), so the frame is bit-exact without emulating the heap;
+//   * frames that fail the check (equal-valued bottlenecks or seeds between two
+//     basins -- ubiquitous in quantised probability maps) are recomputed by an
+//     exact emulation of the reference's binary heap, one workgroup per frame.
+#include "common.h"
+
+namespace pcseg {
+
+constexpr int WS_T = 64;           // tile edge
+constexpr int WS_S = WS_T + 2;     // with halo
+constexpr unsigned WS_INF = 0xFFFFFFFFu;
+
+// order-preserving key of a float32 (the reference compares float64(image)); -0.0 == +0.0
+__device__ __forceinline__ unsigned ws_key(float f)
+{
+    if (f == 0.0f) f = 0.0f;
+    unsigned u = __float_as_uint(f);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return u == WS_INF ? WS_INF - 1 : u;
+}
+
+__global__ void __launch_bounds__(256) ws_init_kernel(const float *__restrict__ img, const int *__restrict__ markers,
+                                                       const uint8_t *__restrict__ mask, unsigned *__restrict__ val,
+                                                       unsigned *__restrict__ L, int *__restrict__ out, int64_t total)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    bool m = mask[i] != 0;
+    unsigned v = m ? ws_key(img[i]) : WS_INF;
+    int mk = m ? markers[i] : 0;
+    val[i] = v;
+    L[i] = mk != 0 ? v : WS_INF;
+    out[i] = mk;
+}
+
+template <typename T>
+__device__ __forceinline__ void ws_load_tile(T *s, const T *__restrict__ g, int r0, int c0, int H, int W, T fill)
+{
+    for (int i = threadIdx.x; i < WS_S * WS_S; i += 256) {
+        int lr = i / WS_S, lc = i % WS_S;
+        int r = r0 + lr - 1, c = c0 + lc - 1;
+        s[i] = (r >= 0 && r < H && c >= 0 && c < W) ? g[(int64_t)r * W + c] : fill;
+    }
+}
+
+__device__ __forceinline__ void ws_mark_neighbours(uint8_t *dirty_out, int b, int tx, int ty, int tilesX, int tilesY)
+{
+    uint8_t *d = dirty_out + (int64_t)b * tilesX * tilesY;
+    if (tx > 0) d[ty * tilesX + tx - 1] = 1;
+    if (tx + 1 < tilesX) d[ty * tilesX + tx + 1] = 1;
+    if (ty > 0) d[(ty - 1) * tilesX + tx] = 1;
+    if (ty + 1 < tilesY) d[(ty + 1) * tilesX + tx] = 1;
+}
+
+// (1) minimax relaxation, tile-local fixed point in LDS
+__global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restrict__ val, unsigned *__restrict__ L,
+                                                        const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
+                                                        int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
+{
+    __shared__ unsigned sL[WS_S * WS_S];
+    __shared__ unsigned sV[WS_S * WS_S];
+    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
+    const int r0 = ty * WS_T, c0 = tx * WS_T;
+    const int64_t fbase = (int64_t)b * H * W;
+    ws_load_tile(sL, L + fbase, r0, c0, H, W, WS_INF);
+    ws_load_tile(sV, val + fbase, r0, c0, H, W, WS_INF);
+    __syncthreads();
+    const int px = (threadIdx.x & 15) * 4 + 1, py = (threadIdx.x >> 4) * 4 + 1;
+    volatile unsigned *vL = sL;
+    bool changed_any = false;
+    for (int iter = 0; iter < 100000; ++iter) {
+        bool changed = false;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int q = 0; q < 16; ++q) {
+                int qq = pass ? 15 - q : q;
+                int i = (py + (qq >> 2)) * WS_S + px + (qq & 3);
+                unsigned v = sV[i];
+                if (v == WS_INF) continue;
+                unsigned cur = vL[i];
+                unsigned m = min(min(vL[i - WS_S], vL[i + WS_S]), min(vL[i - 1], vL[i + 1]));
+                unsigned cand = max(v, m);
+                if (cand < cur) { vL[i] = cand; changed = true; }
+            }
+        }
+        if (!__syncthreads_or(changed)) break;
+        changed_any = true;
+    }
+    if (!changed_any) return;
+    for (int q = 0; q < 16; ++q) {
+        int lr = py + (q >> 2), lc = px + (q & 3);
+        int r = r0 + lr - 1, c = c0 + lc - 1;
+        if (r < H && c < W) L[fbase + (int64_t)r * W + c] = sL[lr * WS_S + lc];
+    }
+    if (threadIdx.x == 0) {
+        ws_mark_neighbours(dirty_out, b, tx, ty, tilesX, tilesY);
+        *any_changed = 1;
+    }
+}
+
+// (2) label propagation along "neighbour with L == Lmin"
+__global__ void __launch_bounds__(256) ws_propagate_kernel(const unsigned *__restrict__ L, int *__restrict__ F,
+                                                            const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
+                                                            int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
+{
+    __shared__ unsigned sL[WS_S * WS_S];
+    __shared__ int sF[WS_S * WS_S];
+    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
+    const int r0 = ty * WS_T, c0 = tx * WS_T;
+    const int64_t fbase = (int64_t)b * H * W;
+    ws_load_tile(sL, L + fbase, r0, c0, H, W, WS_INF);
+    ws_load_tile(sF, (const int *)F + fbase, r0, c0, H, W, 0);
+    __syncthreads();
+    const int px = (threadIdx.x & 15) * 4 + 1, py = (threadIdx.x >> 4) * 4 + 1;
+    volatile int *vF = sF;
+    bool changed_any = false;
+    for (int iter = 0; iter < 100000; ++iter) {
+        bool changed = false;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int q = 0; q < 16; ++q) {
+                int qq = pass ? 15 - q : q;
+                int i = (py + (qq >> 2)) * WS_S + px + (qq & 3);
+                if (sL[i] == WS_INF || vF[i] != 0) continue;
+                unsigned lu = sL[i - WS_S], ll = sL[i - 1], lr = sL[i + 1], ld = sL[i + WS_S];
+                unsigned m = min(min(lu, ld), min(ll, lr));
+                int f = 0;
+                if (lu == m) f = vF[i - WS_S];
+                if (f == 0 && ll == m) f = vF[i - 1];
+                if (f == 0 && lr == m) f = vF[i + 1];
+                if (f == 0 && ld == m) f = vF[i + WS_S];
+                if (f != 0) { vF[i] = f; changed = true; }
+            }
+        }
+        if (!__syncthreads_or(changed)) break;
+        changed_any = true;
+    }
+    if (!changed_any) return;
+    for (int q = 0; q < 16; ++q) {
+        int lr = py + (q >> 2), lc = px + (q & 3);
+        int r = r0 + lr - 1, c = c0 + lc - 1;
+        if (r < H && c < W) F[fbase + (int64_t)r * W + c] = sF[lr * WS_S + lc];
+    }
+    if (threadIdx.x == 0) {
+        ws_mark_neighbours(dirty_out, b, tx, ty, tilesX, tilesY);
+        *any_changed = 1;
+    }
+}
+
+// (3) proof check
+__global__ void __launch_bounds__(256) ws_check_kernel(const unsigned *__restrict__ L, const int *__restrict__ F,
+                                                        const int *__restrict__ markers, const uint8_t *__restrict__ mask,
+                                                        int *__restrict__ tie_flags, int H, int W)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= H || c >= W) return;
+    const int b = blockIdx.z;
+    const int64_t fbase = (int64_t)b * H * W;
+    const int64_t i = fbase + (int64_t)r * W + c;
+    const unsigned l = L[i];
+    if (l == WS_INF) return;                        // outside the mask or unreachable: stays 0
+    if (mask[i] != 0 && markers[i] != 0) return;    // seed: keeps its marker
+    const unsigned lu = r > 0 ? L[i - W] : WS_INF, ld = r + 1 < H ? L[i + W] : WS_INF;
+    const unsigned ll = c > 0 ? L[i - 1] : WS_INF, lr = c + 1 < W ? L[i + 1] : WS_INF;
+    const unsigned m = min(min(lu, ld), min(ll, lr));
+    const int f = F[i];
+    bool ok = f != 0;
+    if (lu == m) ok = ok && F[i - W] == f;
+    if (ll == m) ok = ok && F[i - 1] == f;
+    if (lr == m) ok = ok && F[i + 1] == f;
+    if (ld == m) ok = ok && F[i + W] == f;
+    if (!ok && tie_flags[b] == 0) tie_flags[b] = 1;
+}
+
+__global__ void ws_set_flags_kernel(int *flags, int B, int v)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) flags[i] = v;
+}
+
+// exact emulation of the reference's heap-driven flood for flagged frames
+__global__ void __launch_bounds__(256) ws_exact_kernel(const unsigned *__restrict__ val, const int *__restrict__ markers,
+                                                        const uint8_t *__restrict__ mask, int *__restrict__ out,
+                                                        const int *__restrict__ flags, unsigned long long *__restrict__ heap_key,
+                                                        unsigned *__restrict__ heap_idx, int H, int W)
+{
+    const int b = blockIdx.x;
+    if (flags[b] == 0) return;
+    const int64_t n = (int64_t)H * W;
+    const unsigned *v = val + (int64_t)b * n;
+    const int *mk = markers + (int64_t)b * n;
+    const uint8_t *ms = mask + (int64_t)b * n;
+    int *o = out + (int64_t)b * n;
+    unsigned long long *hk = heap_key + (int64_t)b * n;
+    unsigned *hi = heap_idx + (int64_t)b * n;
+    for (int64_t i = threadIdx.x; i < n; i += 256) o[i] = ms[i] ? mk[i] : 0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int64_t items = 0;
+    unsigned age = 0;
+    auto push = [&](unsigned value, unsigned a, unsigned idx) {
+        unsigned long long key = ((unsigned long long)value << 32) | a;
+        int64_t child = items++;
+        while (child > 0) {
+            int64_t parent = (child + 1) / 2 - 1;
+            unsigned long long pk = hk[parent];
+            if (key < pk) {
+                hk[child] = pk;
+                hi[child] = hi[parent];
+                child = parent;
+            } else break;
+        }
+        hk[child] = key;
+        hi[child] = idx;
+    };
+    for (int64_t i = 0; i < n; ++i)
+        if (o[i] != 0) push(v[i], 0u, (unsigned)i);
+    while (items > 0) {
+        const unsigned e_idx = hi[0];
+        --items;
+        if (items > 0) {
+            // move the last element to the root and sift it down (reference heappop)
+            unsigned long long key = hk[items];
+            unsigned idx = hi[items];
+            int64_t i = 0;
+            for (;;) {
+                int64_t l = 2 * i + 1, r = 2 * i + 2, smallest = i;
+                unsigned long long sk = key;
+                if (l < items) {
+                    unsigned long long lk = hk[l];
+                    if (lk < sk) { smallest = l; sk = lk; }
+                    if (r < items) {
+                        unsigned long long rk = hk[r];
+                        if (rk < sk) { smallest = r; sk = rk; }
+                    }
+                } else break;
+                if (smallest != i) {
+                    hk[i] = sk;
+                    hi[i] = hi[smallest];
+                    i = smallest;
+                } else break;
+            }
+            hk[i] = key;
+            hi[i] = idx;
+        }
+        const int r0 = (int)(e_idx / (unsigned)W), c0 = (int)(e_idx % (unsigned)W);
+        const int lab = o[e_idx];
+        const int dr[4] = {-1, 0, 0, 1}, dc[4] = {0, -1, 1, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int rr = r0 + dr[k], cc = c0 + dc[k];
+            if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+            int64_t q = (int64_t)rr * W + cc;
+            if (!ms[q] || o[q] != 0) continue;
+            ++age;
+            o[q] = lab;
+            push(v[q], age, (unsigned)q);
+        }
+    }
+}
+
+}  // namespace pcseg
+
+using namespace pcseg;
+
+extern "C" {
+
+size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
+{
+    if (!check_shape(B, H, W)) return 0;
+    size_t n = (size_t)B * H * W;
+    int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
+    return 2 * align_up(n * 4) + 2 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + align_up(sizeof(int) * B) +
+           align_up(n * 8) + align_up(n * 4);
+}
+
+int pcseg_watershed4_f32(const float *img, const int32_t *markers, const uint8_t *mask, int32_t *out, int32_t *tie_flags,
+                         int B, int H, int W, int mode, void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(img && markers && mask && out && workspace && check_shape(B, H, W) && mode >= 0 && mode <= 2, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * H * W;
+    const int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
+    const size_t ntiles = (size_t)B * tilesX * tilesY;
+    Carver cv(workspace, workspace_bytes);
+    unsigned *val = cv.take<unsigned>(n);
+    unsigned *L = cv.take<unsigned>(n);
+    uint8_t *dirtyA = cv.take<uint8_t>(ntiles);
+    uint8_t *dirtyB = cv.take<uint8_t>(ntiles);
+    int *changed = cv.take<int>(16);
+    int *flags = cv.take<int>(B);
+    unsigned long long *heap_key = cv.take<unsigned long long>(n);
+    unsigned *heap_idx = cv.take<unsigned>(n);
+    if (!cv.ok()) {
+        set_error("watershed: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(ws_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, markers, mask, val, L, out,
+                       (int64_t)n);
+    PCSEG_CHECK_LAUNCH();
+    if (mode == 1) {
+        hipLaunchKernelGGL(ws_set_flags_kernel, dim3((B + 63) / 64), dim3(64), 0, s, flags, B, 1);
+        PCSEG_CHECK_LAUNCH();
+    } else {
+        dim3 tgrid(tilesX, tilesY, B);
+        for (int phase = 0; phase < 2; ++phase) {
+            PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 1, ntiles, s));
+            uint8_t *din = dirtyA, *dout = dirtyB;
+            for (int round = 0;; round += 4) {
+                PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int), s));
+                for (int k = 0; k < 4; ++k) {
+                    PCSEG_CHECK_HIP(hipMemsetAsync(dout, 0, ntiles, s));
+                    if (phase == 0)
+                        hipLaunchKernelGGL(ws_relax_kernel, tgrid, dim3(256), 0, s, val, L, din, dout, changed, H, W, tilesX, tilesY);
+                    else
+                        hipLaunchKernelGGL(ws_propagate_kernel, tgrid, dim3(256), 0, s, L, out, din, dout, changed, H, W, tilesX,
+                                           tilesY);
+                    PCSEG_CHECK_LAUNCH();
+                    uint8_t *t = din; din = dout; dout = t;
+                }
+                int host_changed = 0;
+                PCSEG_CHECK_HIP(hipMemcpyAsync(&host_changed, changed, sizeof(int), hipMemcpyDeviceToHost, s));
+                PCSEG_CHECK_HIP(hipStreamSynchronize(s));
+                if (!host_changed) break;
+                if (round > 4 * (tilesX * tilesY + 64) * 64) {
+                    set_error("watershed: relaxation did not converge");
+                    return PCSEG_ERR_HIP;
+                }
+            }
+        }
+        PCSEG_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * B, s));
+        dim3 cgrid((W + 63) / 64, (H + 3) / 4, B);
+        hipLaunchKernelGGL(ws_check_kernel, cgrid, dim3(256), 0, s, L, out, markers, mask, flags, H, W);
+        PCSEG_CHECK_LAUNCH();
+    }
+    if (tie_flags) PCSEG_CHECK_HIP(hipMemcpyAsync(tie_flags, flags, sizeof(int) * B, hipMemcpyDeviceToDevice, s));
+    if (mode != 2) {
+        hipLaunchKernelGGL(ws_exact_kernel, dim3(B), dim3(256), 0, s, val, markers, mask, out, flags, heap_key, heap_idx, H, W);
+        PCSEG_CHECK_LAUNCH();
+    }
+    PCSEG_CHECK_HIP(hipStreamSynchronize(s));
+    return PCSEG_OK;
+}
+
+}  // extern "C"

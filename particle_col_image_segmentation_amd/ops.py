@@ -1,0 +1,293 @@
+"""Batched device operators: torch tensors in, torch tensors out, HIP inside.
+
+Every function takes ``(B, H, W)`` (or ``(B, C, H, W)``) CUDA tensors, allocates
+its outputs and workspace through torch's caching allocator and enqueues the
+libpcseg kernels on torch's current stream.  PyTorch is plumbing here (device
+memory + streams); all arithmetic is in ``csrc/*.hip``.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _req(t, dtype, ndim):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("expected a CUDA tensor (the HIP path has no CPU fallback)")
+    if t.dtype == torch.bool and dtype == torch.uint8:
+        t = t.view(torch.uint8)
+    if t.dtype != dtype:
+        raise TypeError("expected dtype %s, got %s" % (dtype, t.dtype))
+    if t.dim() != ndim:
+        raise ValueError("expected %d dims, got shape %s" % (ndim, tuple(t.shape)))
+    return t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def argmax_planes(stack):
+    """class map = argmax over planes + 1 (tiff_analysis.py:639-642 reads this from ilastik)."""
+    stack = _req(stack, torch.float32, 4)
+    B, C, H, W = stack.shape
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=stack.device)
+    lib = _lib.load()
+    _lib.check(lib.pcseg_argmax_planes_f32(_ptr(stack), _ptr(out), B, C, H, W, _stream()), "argmax_planes")
+    return out
+
+
+def median5(x):
+    """scipy.ndimage.median_filter(x, size=5) (tiff_analysis.py:122, 643)."""
+    x = _req(x, torch.uint8, 3)
+    B, H, W = x.shape
+    out = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.pcseg_median5_u8(_ptr(x), _ptr(out), B, H, W, _stream()), "median5")
+    return out
+
+
+def _ccl(fn_name, x):
+    x = _req(x, torch.uint8, 3)
+    B, H, W = x.shape
+    lib = _lib.load()
+    labels = torch.empty((B, H, W), dtype=torch.int32, device=x.device)
+    counts = torch.empty((B,), dtype=torch.int32, device=x.device)
+    nbytes = lib.pcseg_ccl_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, x.device)
+    _lib.check(getattr(lib, fn_name)(_ptr(x), _ptr(labels), _ptr(counts), B, H, W, _ptr(ws), nbytes, _stream()), fn_name)
+    return labels, counts
+
+
+def label_equal8(x):
+    """skimage.measure.label(int image): equal-valued 8-connected components (tiff_analysis.py:743)."""
+    return _ccl("pcseg_ccl8_equal_u8", x)
+
+
+def label_bool8(x):
+    """skimage.measure.label(bool image) (tiff_analysis.py:260, 829; refine_boundaries.py:64)."""
+    return _ccl("pcseg_ccl8_bool", x)
+
+
+def label_bool4(x):
+    """scipy.ndimage.label(bool image), 4-connectivity."""
+    return _ccl("pcseg_ccl4_bool", x)
+
+
+def compact_labels(roots):
+    roots = _req(roots, torch.int32, 3)
+    B, H, W = roots.shape
+    lib = _lib.load()
+    labels = torch.empty_like(roots)
+    counts = torch.empty((B,), dtype=torch.int32, device=roots.device)
+    nbytes = lib.pcseg_ccl_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, roots.device)
+    _lib.check(lib.pcseg_compact_labels(_ptr(roots), _ptr(labels), _ptr(counts), B, H, W, _ptr(ws), nbytes, _stream()),
+               "compact_labels")
+    return labels, counts
+
+
+def region_reduce(labels, counts=None, cls=None, planes=None, cap=None):
+    """regionprops sums + optional class at first pixel + optional per-label plane sums.
+
+    Returns (stats int64 (B,cap,8), cls_out uint8 (B,cap) | None, sums float64 (B,cap,C) | None,
+    overflow int32 (B,))."""
+    labels = _req(labels, torch.int32, 3)
+    B, H, W = labels.shape
+    dev = labels.device
+    if cap is None:
+        if counts is None:
+            raise ValueError("cap or counts is required")
+        cap = max(1, int(counts.max().item()))
+    stats = torch.zeros((B, cap, 8), dtype=torch.int64, device=dev)
+    cls_out = None
+    sums = None
+    C = 0
+    if cls is not None:
+        cls = _req(cls, torch.uint8, 3)
+        cls_out = torch.zeros((B, cap), dtype=torch.uint8, device=dev)
+    if planes is not None:
+        planes = _req(planes, torch.float32, 4)
+        C = planes.shape[1]
+        sums = torch.zeros((B, cap, C), dtype=torch.float64, device=dev)
+    if counts is not None:
+        counts = _req(counts, torch.int32, 1)
+    overflow = torch.zeros((B,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.pcseg_region_reduce_n(_ptr(labels), _ptr(counts), _ptr(cls), _ptr(planes), C, B, H, W, cap,
+                                         _ptr(stats), _ptr(cls_out), _ptr(sums), _ptr(overflow), _stream()),
+               "region_reduce")
+    return stats, cls_out, sums, overflow
+
+
+def threshold_lt(img, threshold):
+    """binary_mask = boundary_map < threshold (refine_boundaries.py:44-45)."""
+    img = _req(img, torch.float32, 3)
+    B, H, W = img.shape
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=img.device)
+    lib = _lib.load()
+    _lib.check(lib.pcseg_threshold_lt_f32(_ptr(img), float(threshold), _ptr(out), B, H, W, _stream()), "threshold_lt")
+    return out
+
+
+def edt_sq(mask, cap=-1):
+    """exact squared EDT of a 0/1 mask (refine_boundaries.py:60, tiff_analysis.py:996)."""
+    mask = _req(mask, torch.uint8, 3)
+    B, H, W = mask.shape
+    lib = _lib.load()
+    d2 = torch.empty((B, H, W), dtype=torch.int32, device=mask.device)
+    nbytes = lib.pcseg_edt_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, mask.device)
+    _lib.check(lib.pcseg_edt_sq_u8(_ptr(mask), _ptr(d2), B, H, W, int(cap), _ptr(ws), nbytes, _stream()), "edt_sq")
+    return d2
+
+
+def edt_sq_lt(img, threshold, want_mask=True):
+    """fused threshold + squared EDT (refine_boundaries.py:44-45, 60)."""
+    img = _req(img, torch.float32, 3)
+    B, H, W = img.shape
+    lib = _lib.load()
+    d2 = torch.empty((B, H, W), dtype=torch.int32, device=img.device)
+    mask = torch.empty((B, H, W), dtype=torch.uint8, device=img.device) if want_mask else None
+    nbytes = lib.pcseg_edt_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, img.device)
+    _lib.check(lib.pcseg_edt_sq_lt_f32(_ptr(img), float(threshold), _ptr(d2), _ptr(mask), B, H, W, _ptr(ws), nbytes,
+                                       _stream()), "edt_sq_lt")
+    return d2, mask
+
+
+def dilate_disk(x, value_bits, radius):
+    """binary_dilation(((value_bits >> x) & 1), disk(radius)) (tiff_analysis.py:827-828, 990)."""
+    x = _req(x, torch.uint8, 3)
+    B, H, W = x.shape
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    nbytes = lib.pcseg_edt_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, x.device)
+    _lib.check(lib.pcseg_dilate_disk_u8(_ptr(x), ctypes.c_uint64(int(value_bits)), int(radius), _ptr(out), B, H, W,
+                                        _ptr(ws), nbytes, _stream()), "dilate_disk")
+    return out
+
+
+def fill_particle(ds, particle_label, cell_label, overlap_label, dilation_radius, dist_threshold, overlap_area=None):
+    """fill_particle_area (tiff_analysis.py:982-1015); overlap_area int64 (B,) is accumulated in place."""
+    ds = _req(ds, torch.uint8, 3)
+    B, H, W = ds.shape
+    lib = _lib.load()
+    out = torch.empty_like(ds)
+    if overlap_area is None:
+        overlap_area = torch.zeros((B,), dtype=torch.int64, device=ds.device)
+    nbytes = lib.pcseg_edt_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, ds.device)
+    _lib.check(lib.pcseg_fill_particle(_ptr(ds), _ptr(out), int(particle_label), int(cell_label), int(overlap_label),
+                                       int(dilation_radius), int(dist_threshold), _ptr(overlap_area), B, H, W,
+                                       _ptr(ws), nbytes, _stream()), "fill_particle")
+    return out, overlap_area
+
+
+def fill_holes(mask):
+    """scipy.ndimage.binary_fill_holes (tiff_analysis.py:880)."""
+    mask = _req(mask, torch.uint8, 3)
+    B, H, W = mask.shape
+    lib = _lib.load()
+    out = torch.empty_like(mask)
+    nbytes = lib.pcseg_fill_holes_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, mask.device)
+    _lib.check(lib.pcseg_fill_holes(_ptr(mask), _ptr(out), B, H, W, _ptr(ws), nbytes, _stream()), "fill_holes")
+    return out
+
+
+def local_maxima(img, want_mask=True, want_markers=True):
+    """skimage.morphology.local_maxima + measure.label on an int32 image (refine_boundaries.py:63-64)."""
+    img = _req(img, torch.int32, 3)
+    B, H, W = img.shape
+    lib = _lib.load()
+    is_max = torch.empty((B, H, W), dtype=torch.uint8, device=img.device) if want_mask else None
+    markers = torch.empty((B, H, W), dtype=torch.int32, device=img.device) if want_markers else None
+    counts = torch.empty((B,), dtype=torch.int32, device=img.device)
+    nbytes = lib.pcseg_local_maxima_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, img.device)
+    _lib.check(lib.pcseg_local_maxima_i32(_ptr(img), _ptr(is_max), _ptr(markers), _ptr(counts), B, H, W, _ptr(ws),
+                                          nbytes, _stream()), "local_maxima")
+    return is_max, markers, counts
+
+
+def watershed(img, markers, mask, mode=0):
+    """skimage.segmentation.watershed(img, markers, mask=mask) (refine_boundaries.py:73).
+
+    Returns (labels int32, tie_flags int32 (B,)): tie_flags[b] = 1 where the parallel flood could not be
+    proven exact (mode 0 re-runs those frames with the exact sequential flood)."""
+    img = _req(img, torch.float32, 3)
+    markers = _req(markers, torch.int32, 3)
+    mask = _req(mask, torch.uint8, 3)
+    B, H, W = img.shape
+    lib = _lib.load()
+    out = torch.empty((B, H, W), dtype=torch.int32, device=img.device)
+    flags = torch.zeros((B,), dtype=torch.int32, device=img.device)
+    nbytes = lib.pcseg_watershed_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, img.device)
+    _lib.check(lib.pcseg_watershed4_f32(_ptr(img), _ptr(markers), _ptr(mask), _ptr(out), _ptr(flags), B, H, W, int(mode),
+                                        _ptr(ws), nbytes, _stream()), "watershed")
+    return out, flags
+
+
+def merge_groups(dilated_labels, stats, select, n_regions):
+    """get_merged_regions grouping (tiff_analysis.py:843-878): group id per region, 0 = dropped."""
+    dl = _req(dilated_labels, torch.int32, 3)
+    stats = _req(stats, torch.int64, 3)
+    select = _req(select, torch.uint8, 2)
+    n_regions = _req(n_regions, torch.int32, 1)
+    B, H, W = dl.shape
+    cap = stats.shape[1]
+    lib = _lib.load()
+    group_of = torch.zeros((B, cap), dtype=torch.int32, device=dl.device)
+    n_groups = torch.zeros((B,), dtype=torch.int32, device=dl.device)
+    nbytes = lib.pcseg_merge_groups_workspace_bytes(B, cap)
+    ws = _ws(nbytes, dl.device)
+    _lib.check(lib.pcseg_merge_groups(_ptr(dl), _ptr(stats), _ptr(select), _ptr(n_regions), _ptr(group_of), _ptr(n_groups),
+                                      B, H, W, cap, _ptr(ws), nbytes, _stream()), "merge_groups")
+    return group_of, n_groups
+
+
+def remove_overlapping(dapi, other, threshold):
+    """combine_cell_positions_and_clusters (tiff_analysis.py:252-287)."""
+    dapi = _req(dapi, torch.uint8, 3)
+    other = _req(other, torch.uint8, 3)
+    B, H, W = dapi.shape
+    lib = _lib.load()
+    out = torch.empty_like(dapi)
+    nbytes = lib.pcseg_overlap_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, dapi.device)
+    _lib.check(lib.pcseg_remove_overlapping(_ptr(dapi), _ptr(other), float(threshold), _ptr(out), B, H, W, _ptr(ws),
+                                            nbytes, _stream()), "remove_overlapping")
+    return out
+
+
+def otsu_hist(img):
+    """256-bin histogram of each frame over its own [min, max] (north_star extension X1)."""
+    img = _req(img, torch.float32, 3)
+    B, H, W = img.shape
+    lib = _lib.load()
+    hist = torch.zeros((B, 256), dtype=torch.int64, device=img.device)
+    lohi = torch.zeros((B, 2), dtype=torch.float32, device=img.device)
+    _lib.check(lib.pcseg_otsu_hist_f32(_ptr(img), _ptr(hist), _ptr(lohi), B, H, W, _stream()), "otsu_hist")
+    return hist, lohi
+
+
+def morph3x3(mask, erode):
+    """3x3 binary erosion / dilation (north_star extension X2)."""
+    mask = _req(mask, torch.uint8, 3)
+    B, H, W = mask.shape
+    lib = _lib.load()
+    out = torch.empty_like(mask)
+    _lib.check(lib.pcseg_morph3x3(_ptr(mask), _ptr(out), int(bool(erode)), B, H, W, _stream()), "morph3x3")
+    return out

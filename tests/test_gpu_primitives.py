@@ -1,0 +1,303 @@
+"""HIP kernels (through the C ABI) against the CPU oracle and the golden vectors.
+Bit-exact for every integer / label / mask result."""
+import numpy as np
+import pytest
+
+from conftest import golden_cases, load_golden
+from oracle import oracle as orc
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the HIP path has no CPU fallback")
+    from particle_col_image_segmentation_amd import ops as _ops
+    return _ops
+
+
+def dev(a, dtype=None):
+    a = np.ascontiguousarray(a)
+    if a.dtype == bool:
+        a = a.astype(np.uint8)
+    t = torch.from_numpy(a)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def one(a, dtype=None):
+    return dev(a, dtype)[None]
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+RNG = np.random.default_rng(99)
+
+
+def test_argmax(ops):
+    from particle_col_image_segmentation_amd import synth
+    for shape in [(3, 5, 33, 47), (2, 5, 64, 64), (1, 7, 17, 23)]:
+        st = RNG.random(shape).astype(np.float32)
+        got = host(ops.argmax_planes(dev(st)))
+        np.testing.assert_array_equal(got, np.argmax(st, axis=1) + 1)
+    st = synth.gen_batch(5, 2, 128, 128)
+    np.testing.assert_array_equal(host(ops.argmax_planes(dev(st))), synth.class_map_from_stack(st))
+
+
+def test_median(ops, primitives):
+    for c in golden_cases(primitives, "median"):
+        np.testing.assert_array_equal(host(ops.median5(one(c["inp"])))[0], c["out"])
+    for (b, h, w, hi) in [(3, 100, 131, 6), (2, 257, 64, 256), (1, 1024, 1024, 6), (2, 70, 300, 17)]:
+        a = RNG.integers(0, hi, (b, h, w)).astype(np.uint8)
+        got = host(ops.median5(dev(a)))
+        for i in range(b):
+            np.testing.assert_array_equal(got[i], orc.median_filter(a[i]))
+
+
+@pytest.mark.parametrize("kind,fn,conn", [("label_eq8", "label_equal8", None), ("label_bool8", "label_bool8", None),
+                                          ("label_bool4", "label_bool4", 1)])
+def test_label_golden(ops, primitives, kind, fn, conn):
+    for c in golden_cases(primitives, kind):
+        lab, cnt = getattr(ops, fn)(one(c["inp"]))
+        np.testing.assert_array_equal(host(lab)[0], c["out"])
+        assert int(cnt[0]) == int(c["n"])
+
+
+def test_label_large(ops):
+    from particle_col_image_segmentation_amd import synth
+    for (b, h, w, k, p) in [(3, 200, 333, 3, 0.6), (2, 512, 512, 2, 0.45), (1, 97, 1030, 4, 0.8), (2, 65, 129, 1, 0.55)]:
+        a = (RNG.integers(1, k + 1, (b, h, w)) * (RNG.random((b, h, w)) < p)).astype(np.uint8)
+        lab, cnt = ops.label_equal8(dev(a))
+        lb8, cb8 = ops.label_bool8(dev(a))
+        lb4, cb4 = ops.label_bool4(dev(a))
+        for i in range(b):
+            exp, n = orc.label(a[i], return_num=True)
+            np.testing.assert_array_equal(host(lab)[i], exp)
+            assert int(cnt[i]) == n
+            exp, n = orc.label(a[i] > 0, return_num=True)
+            np.testing.assert_array_equal(host(lb8)[i], exp)
+            assert int(cb8[i]) == n
+            exp, n = orc.label(a[i] > 0, connectivity=1, return_num=True)
+            np.testing.assert_array_equal(host(lb4)[i], exp)
+            assert int(cb4[i]) == n
+    st = synth.gen_batch(31, 2, 512, 512)
+    cm = np.stack([orc.median_filter(c) for c in synth.class_map_from_stack(st)])
+    lab, cnt = ops.label_equal8(dev(cm))
+    for i in range(2):
+        exp, n = orc.label(cm[i], return_num=True)
+        np.testing.assert_array_equal(host(lab)[i], exp)
+        assert int(cnt[i]) == n
+    # one huge spiral component + empty + full frames
+    sp = np.zeros((3, 200, 200), np.uint8)
+    sp[1] = 1
+    r = np.arange(200)
+    sp[2][::2, :] = 1
+    sp[2][1::4, -1] = 1
+    sp[2][3::4, 0] = 1
+    lab, cnt = ops.label_bool4(dev(sp))
+    for i in range(3):
+        exp, n = orc.label(sp[i] > 0, connectivity=1, return_num=True)
+        np.testing.assert_array_equal(host(lab)[i], exp)
+        assert int(cnt[i]) == n
+
+
+def test_region_reduce(ops):
+    from particle_col_image_segmentation_amd import synth
+    for (b, h, w) in [(2, 64, 64), (2, 200, 333), (1, 512, 512)]:
+        st = synth.gen_batch(40, b, h, w)
+        cm = np.stack([orc.median_filter(c) for c in synth.class_map_from_stack(st)])
+        labs = np.stack([orc.label(c) for c in cm])
+        counts = torch.tensor([int(l.max()) for l in labs], dtype=torch.int32).cuda()
+        stats, cls_out, sums, ovf = ops.region_reduce(dev(labs), counts, dev(cm), dev(st))
+        assert int(ovf.sum()) == 0
+        for i in range(b):
+            n = int(labs[i].max())
+            tab = orc.region_table(labs[i])
+            np.testing.assert_array_equal(host(stats)[i, :n], tab)
+            firsts = tab[:, 7]
+            np.testing.assert_array_equal(host(cls_out)[i, :n], cm[i].ravel()[firsts])
+            np.testing.assert_allclose(host(sums)[i, :n], orc.channel_sums(labs[i], st[i]), rtol=1e-12, atol=0)
+    # capacity overflow is reported, rows below cap stay correct
+    labs = np.stack([orc.label(RNG.random((50, 60)) < 0.3)])
+    stats, _, _, ovf = ops.region_reduce(dev(labs), cap=5)
+    assert int(ovf[0]) == 1
+    np.testing.assert_array_equal(host(stats)[0], orc.region_table(labs[0])[:5])
+
+
+def test_edt(ops, primitives):
+    for c in golden_cases(primitives, "edt"):
+        d2 = host(ops.edt_sq(one(c["inp"])))[0]
+        np.testing.assert_array_equal(np.sqrt(d2.astype(np.float64)), c["out"])
+    for (b, h, w, p) in [(3, 100, 131, 0.97), (2, 257, 300, 0.999), (2, 33, 1025, 0.9), (1, 1024, 1024, 0.9995),
+                         (2, 40, 40, 1.0), (2, 31, 65, 0.5)]:
+        m = RNG.random((b, h, w)) < p
+        d2 = host(ops.edt_sq(dev(m)))
+        dc = host(ops.edt_sq(dev(m), cap=50))
+        for i in range(b):
+            exp = orc.edt_sq(m[i])
+            np.testing.assert_array_equal(d2[i], exp)
+            np.testing.assert_array_equal(dc[i], np.minimum(exp, 51))
+
+
+def test_edt_fused_threshold(ops):
+    img = RNG.random((2, 120, 77)).astype(np.float32)
+    img[0, 5, 5] = 0.5
+    d2, mask = ops.edt_sq_lt(dev(img), 0.5)
+    np.testing.assert_array_equal(host(mask).astype(bool), img < 0.5)
+    np.testing.assert_array_equal(host(ops.threshold_lt(dev(img), 0.5)).astype(bool), img < 0.5)
+    for i in range(2):
+        np.testing.assert_array_equal(host(d2)[i], orc.edt_sq(img[i] < 0.5))
+
+
+def test_dilate(ops, primitives):
+    for c in golden_cases(primitives, "dilate"):
+        x = c["inp"].astype(np.uint8) * 3
+        for rad in (2, 5, 20):
+            got = host(ops.dilate_disk(one(x), 1 << 3, rad))[0]
+            np.testing.assert_array_equal(got.astype(bool), c["r%d" % rad])
+    z = RNG.integers(1, 6, (2, 90, 140)).astype(np.uint8) * (RNG.random((2, 90, 140)) < 0.02)
+    got = host(ops.dilate_disk(dev(z.astype(np.uint8)), (1 << 1) | (1 << 2), 2))
+    for i in range(2):
+        np.testing.assert_array_equal(got[i].astype(bool), orc.binary_dilation_disk((z[i] == 1) | (z[i] == 2), 2))
+
+
+def test_fill_particle(ops):
+    from particle_col_image_segmentation_amd import synth
+    st = synth.gen_batch(60, 3, 128, 160)
+    cm = np.stack([orc.median_filter(c) for c in synth.class_map_from_stack(st)])
+    cm[2][cm[2] == 3] = 5  # a frame without any particle pixel (scipy's degenerate EDT)
+    cm[2][0, 0] = 1
+    cm[2][0, 1] = 1
+    cm[2][1, 0] = 1
+    out, area = ops.fill_particle(dev(cm), 3, 1, 3, 20, 2)
+    for i in range(3):
+        exp, ov = orc.fill_particle_area(cm[i], 3, 1, 3)
+        np.testing.assert_array_equal(host(out)[i], exp)
+        assert int(area[i]) == ov
+    assert int(area[2]) == 2
+
+
+def test_fill_holes(ops, primitives):
+    for c in golden_cases(primitives, "fill"):
+        np.testing.assert_array_equal(host(ops.fill_holes(one(c["inp"])))[0].astype(bool), c["out"])
+    m = RNG.random((2, 150, 210)) < 0.58
+    got = host(ops.fill_holes(dev(m)))
+    for i in range(2):
+        np.testing.assert_array_equal(got[i].astype(bool), orc.binary_fill_holes(m[i]))
+
+
+def test_local_maxima(ops, primitives):
+    for c in golden_cases(primitives, "locmax"):
+        d2 = orc.edt_sq(c["mask"])
+        is_max, markers, cnt = ops.local_maxima(one(d2))
+        np.testing.assert_array_equal(host(is_max)[0].astype(bool), c["out"])
+        np.testing.assert_array_equal(host(markers)[0], c["markers"])
+        assert int(cnt[0]) == int(c["markers"].max())
+    for c in golden_cases(primitives, "locmax_int"):
+        is_max, markers, cnt = ops.local_maxima(one(c["inp"]))
+        np.testing.assert_array_equal(host(is_max)[0].astype(bool), c["out"])
+        np.testing.assert_array_equal(host(markers)[0], orc.label(c["out"]))
+    a = RNG.integers(0, 3, (2, 130, 200)).astype(np.int32)
+    is_max, markers, cnt = ops.local_maxima(dev(a))
+    for i in range(2):
+        lm = orc.local_maxima(a[i])
+        np.testing.assert_array_equal(host(is_max)[i].astype(bool), lm)
+        np.testing.assert_array_equal(host(markers)[i], orc.label(lm))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_watershed_golden(ops, primitives, mode):
+    n_flagged = 0
+    for c in golden_cases(primitives, "ws"):
+        out, flags = ops.watershed(one(c["img"]), one(c["markers"]), one(c["mask"]), mode=mode)
+        np.testing.assert_array_equal(host(out)[0], c["out"])
+        n_flagged += int(flags[0])
+    if mode == 0:
+        assert n_flagged > 0  # quantised cases must have gone through the exact path
+
+
+def test_watershed_parallel_path_is_proven(ops):
+    """Tie-free frames: the parallel flood alone (mode 2) must already be exact wherever it says so."""
+    from particle_col_image_segmentation_amd import synth
+    st = synth.gen_batch(70, 3, 192, 256)
+    bm = np.ascontiguousarray(st[:, 3])
+    refs = [orc.refine_boundaries(b) for b in bm]
+    mk = np.stack([r["markers"] for r in refs])
+    ms = np.stack([r["binary_mask"] for r in refs])
+    out, flags = ops.watershed(dev(bm), dev(mk), dev(ms), mode=2)
+    proven = 0
+    for i in range(3):
+        if int(flags[i]) == 0:
+            np.testing.assert_array_equal(host(out)[i], refs[i]["labels"])
+            proven += 1
+    assert proven >= 2
+    out, _ = ops.watershed(dev(bm), dev(mk), dev(ms), mode=0)
+    for i in range(3):
+        np.testing.assert_array_equal(host(out)[i], refs[i]["labels"])
+
+
+def test_refine_chain_batch(ops):
+    from particle_col_image_segmentation_amd import synth
+    for ties in (False, True):
+        st = synth.gen_batch(80, 2, 128, 128, ties=ties)
+        bm = np.ascontiguousarray(st[:, 3])
+        d2, mask = ops.edt_sq_lt(dev(bm), 0.5)
+        is_max, markers, cnt = ops.local_maxima(d2)
+        labels, flags = ops.watershed(dev(bm), markers, mask)
+        for i in range(2):
+            ref = orc.refine_boundaries(bm[i])
+            np.testing.assert_array_equal(host(mask)[i].astype(bool), ref["binary_mask"])
+            np.testing.assert_array_equal(np.sqrt(host(d2)[i].astype(np.float64)), ref["distance"])
+            np.testing.assert_array_equal(host(is_max)[i].astype(bool), ref["local_max"])
+            np.testing.assert_array_equal(host(markers)[i], ref["markers"])
+            np.testing.assert_array_equal(host(labels)[i], ref["labels"])
+
+
+def test_merge_groups(ops):
+    from particle_col_image_segmentation_amd import synth
+    st = synth.gen_batch(90, 2, 160, 160)
+    cm = np.stack([orc.median_filter(c) for c in synth.class_map_from_stack(st)])
+    labs = np.stack([orc.label(c) for c in cm])
+    counts = torch.tensor([int(l.max()) for l in labs], dtype=torch.int32).cuda()
+    stats, cls_out, _, _ = ops.region_reduce(dev(labs), counts, dev(cm))
+    dil = ops.dilate_disk(dev(cm), (1 << 1) | (1 << 2), 2)
+    dl, _ = ops.label_bool8(dil)
+    area = stats[:, :, 0]
+    select = ((cls_out == 1) | (cls_out == 2)) & (area >= 20)
+    group_of, n_groups = ops.merge_groups(dl, stats, select.to(torch.uint8), counts)
+    for i in range(2):
+        regs = [r for r in orc.regionprops(labs[i]) if cm[i][r.first] in (1, 2) and r.area >= 20]
+        groups, _ = orc.get_merged_regions((cm[i] == 1) | (cm[i] == 2), regs)
+        exp = np.zeros(int(counts[i]), np.int32)
+        for gi, g in enumerate(groups):
+            for r in g["regions"]:
+                exp[r.label - 1] = gi + 1
+        np.testing.assert_array_equal(host(group_of)[i, :int(counts[i])], exp)
+        assert int(n_groups[i]) == len(groups)
+
+
+def test_remove_overlapping(ops):
+    g = load_golden("overlap")
+    for i in range(2):
+        out = ops.remove_overlapping(one(g["ov_%d_dapi" % i]), one(g["ov_%d_other" % i]), 0.1)
+        np.testing.assert_array_equal(host(out)[0], g["ov_%d_out" % i])
+
+
+def test_extensions_otsu_morph(ops):
+    """north_star extensions without a reference call site: checked against the oracle only (parity unpinned)."""
+    m = RNG.random((2, 50, 70)) < 0.5
+    for erode in (0, 1):
+        got = host(ops.morph3x3(dev(m), erode))
+        for i in range(2):
+            np.testing.assert_array_equal(got[i].astype(bool), orc.morph3x3(m[i], erode))
+    img = RNG.random((2, 100, 90)).astype(np.float32)
+    hist, lohi = ops.otsu_hist(dev(img))
+    for i in range(2):
+        thr, h = orc.threshold_otsu(img[i])
+        np.testing.assert_array_equal(host(hist)[i], h)
+        assert float(lohi[i, 0]) == img[i].min() and float(lohi[i, 1]) == img[i].max()
