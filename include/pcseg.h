@@ -106,8 +106,10 @@ int pcseg_threshold_lt_f32(const float *img, float threshold, uint8_t *mask, int
 size_t pcseg_edt_workspace_bytes(int B, int H, int W);
 int pcseg_edt_sq_u8(const uint8_t *mask, int32_t *d2, int B, int H, int W, int cap,
                     void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
-/* fused R1 + R2: mask = img < threshold (also written to mask_out if not NULL) */
-int pcseg_edt_sq_lt_f32(const float *img, float threshold, int32_t *d2, uint8_t *mask_out,
+/* fused R1 + R2: mask = img < threshold (also written to mask_out if not NULL).
+ * frame_stride = float32 elements between consecutive frames of img (0 = H*W),
+ * so that a plane of a (B,C,H,W) stack is read in place (refine_boundaries.py:34). */
+int pcseg_edt_sq_lt_f32(const float *img, int64_t frame_stride, float threshold, int32_t *d2, uint8_t *mask_out,
                         int B, int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
 
 /* ---- A6: skimage.morphology.binary_dilation(binary, disk(radius))
@@ -143,23 +145,50 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
  * [sync]  mode 0: parallel flood + proof check, frames that fail the check
  * are re-run by the exact sequential priority flood; mode 1: exact sequential
  * flood for every frame; mode 2: parallel flood only (tie_flags tells which
- * frames are NOT proven exact).  tie_flags: device int32[B] (may be NULL). */
+ * frames are NOT proven exact).  tie_flags: device int32[B] (may be NULL).
+ * frame_stride: as for pcseg_edt_sq_lt_f32 (0 = H*W). */
 size_t pcseg_watershed_workspace_bytes(int B, int H, int W);
-int pcseg_watershed4_f32(const float *img, const int32_t *markers, const uint8_t *mask, int32_t *out,
-                         int32_t *tie_flags, int B, int H, int W, int mode,
+int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *markers, const uint8_t *mask,
+                         int32_t *out, int32_t *tie_flags, int B, int H, int W, int mode,
                          void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
 
 /* ---- A6 tail: get_merged_regions grouping (tiff_analysis.py:843-878).
- * For frame b and region r < n_regions[b] with select[b][r] != 0: key =
- * dilated_labels at the truncated centroid; regions sharing a non-zero key
- * form one group, groups numbered 1.. in the order of their first member;
- * group_of[b][r] = group id or 0 (unselected / key 0).  n_groups: int32[B].
- * stats is the (B, cap, 8) table of pcseg_region_reduce. */
-size_t pcseg_merge_groups_workspace_bytes(int B, int cap);
-int pcseg_merge_groups(const int32_t *dilated_labels, const int64_t *stats, const uint8_t *select,
-                       const int32_t *n_regions, int32_t *group_of, int32_t *n_groups,
-                       int B, int H, int W, int cap, void *workspace, size_t workspace_bytes,
+ * region_list[b][k] (k < n_list[b]) is the reference's og_cell_regions as
+ * 0-based row indices into the (B, cap, 8) stats table, in list order.  key =
+ * dilated_labels at the truncated centroid; list entries sharing a non-zero
+ * key form one group, groups numbered 1.. in the order of their first member;
+ * group_of[b][k] = group id or 0 (centroid on a zero pixel -> dropped, :848).
+ * region_list / group_of: int32 (B, list_cap); n_list / n_groups: int32[B]. */
+size_t pcseg_merge_groups_workspace_bytes(int B, int list_cap);
+int pcseg_merge_groups(const int32_t *dilated_labels, const int64_t *stats, const int32_t *region_list,
+                       const int32_t *n_list, int32_t *group_of, int32_t *n_groups,
+                       int B, int H, int W, int cap, int list_cap, void *workspace, size_t workspace_bytes,
                        pcseg_stream_t stream);
+
+/* member sums of the groups: group_stats int64 (B, list_cap, 8) = area, sum_row,
+ * sum_col, min_row, min_col, max_row+1, max_col+1, members (tiff_analysis.py:855-872) */
+int pcseg_group_reduce(const int64_t *stats, const int32_t *region_list, const int32_t *n_list,
+                       const int32_t *group_of, const int32_t *n_groups, int64_t *group_stats,
+                       int B, int H, int W, int cap, int list_cap, pcseg_stream_t stream);
+
+/* ---- A3 tail + A4: the per-region loop of get_cell_positions_and_areas
+ * (tiff_analysis.py:754-781) and the region lists get_cell_clusters_from_distances
+ * builds (:794-796).  Class tables are HOST arrays: class_slot[256] maps a class
+ * value to a cell-type slot (255 = none), class_particle[256] flags "Particle",
+ * min_cell / min_cluster [n_slots] are MIN_CELL_AREA / MIN_CLUSTER_AREA (:54-60).
+ * Outputs (device): kind (B,cap) 0 none / 1 cell / 2 cluster; slot_of (B,cap);
+ * cells (B,cap) = 1 for cells, int(area // mean cell area) for clusters, -1 when
+ * the reference would raise (clusters but no single cell; nan_flag[b] = 1);
+ * particle_area int64[B]; type_stats int64 (B,4,4) = n_cells, n_clusters,
+ * sum of cell areas, first region index; region_list int32 (B,5,cap): per slot
+ * cells then clusters in label order, row 4 = the "combined" list (types in the
+ * order of their first region); n_list int32 (B,5). */
+int pcseg_classify_regions(const int64_t *stats, const uint8_t *cls_out, const int32_t *counts,
+                           const uint8_t *class_slot, const uint8_t *class_particle,
+                           const int32_t *min_cell, const int32_t *min_cluster, int n_slots,
+                           uint8_t *kind, uint8_t *slot_of, int32_t *cells, int64_t *particle_area,
+                           int64_t *type_stats, int32_t *region_list, int32_t *n_list, int32_t *nan_flag,
+                           int B, int cap, pcseg_stream_t stream);
 
 /* ---- C6: combine_cell_positions_and_clusters (tiff_analysis.py:252-287):
  * out = dapi with every 8-connected component of (dapi == 1) whose overlap

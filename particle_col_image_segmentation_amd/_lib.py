@@ -5,7 +5,7 @@ every compute call raises -- loudly, by design.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_uint64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcseg.so")
@@ -35,7 +35,7 @@ SIGNATURES = {
     "pcseg_threshold_lt_f32": (c_int, [_P, c_float, _P, _I, _I, _I, _P]),
     "pcseg_edt_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_edt_sq_u8": (c_int, [_P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),
-    "pcseg_edt_sq_lt_f32": (c_int, [_P, c_float, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
+    "pcseg_edt_sq_lt_f32": (c_int, [_P, c_int64, c_float, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_dilate_disk_u8": (c_int, [_P, c_uint64, _I, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_fill_particle": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_fill_holes_workspace_bytes": (c_size_t, [_I, _I, _I]),
@@ -43,9 +43,11 @@ SIGNATURES = {
     "pcseg_local_maxima_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_local_maxima_i32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_watershed_workspace_bytes": (c_size_t, [_I, _I, _I]),
-    "pcseg_watershed4_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),
+    "pcseg_watershed4_f32": (c_int, [_P, c_int64, _P, _P, _P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_merge_groups_workspace_bytes": (c_size_t, [_I, _I]),
-    "pcseg_merge_groups": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),
+    "pcseg_merge_groups": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, c_size_t, _P]),
+    "pcseg_group_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "pcseg_classify_regions": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "pcseg_overlap_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_remove_overlapping": (c_int, [_P, _P, c_double, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_otsu_hist_f32": (c_int, [_P, _P, _P, _I, _I, _I, _P]),

@@ -18,25 +18,26 @@ constexpr unsigned G_INF = 0xFFFFu;  // "no zero pixel in this column"
 // ---- foreground predicates (distance is measured TO the nearest non-foreground pixel)
 struct FgNzU8 {
     const uint8_t *p;
-    __device__ __forceinline__ bool operator()(int64_t i) const { return p[i] != 0; }
+    __device__ __forceinline__ bool operator()(int b, int64_t pix, int64_t n) const { return p[b * n + pix] != 0; }
 };
 struct FgLtF32 {
     const float *p;
     float thr;
     uint8_t *mask_out;
-    __device__ __forceinline__ bool operator()(int64_t i) const
+    int64_t frame_stride;  // elements between frames of p (a plane inside a (B,C,H,W) stack)
+    __device__ __forceinline__ bool operator()(int b, int64_t pix, int64_t n) const
     {
-        bool m = p[i] < thr;
-        if (mask_out) mask_out[i] = m;
+        bool m = p[b * frame_stride + pix] < thr;
+        if (mask_out) mask_out[b * n + pix] = m;
         return m;
     }
 };
 struct FgNotInSetU8 {
     const uint8_t *p;
     unsigned long long bits;
-    __device__ __forceinline__ bool operator()(int64_t i) const
+    __device__ __forceinline__ bool operator()(int b, int64_t pix, int64_t n) const
     {
-        unsigned v = p[i];
+        unsigned v = p[b * n + pix];
         return !(v < 64 && ((bits >> v) & 1ull));
     }
 };
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(256) edt_bits_kernel(Fg fg, unsigned *__restri
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int ch = blockIdx.y, b = blockIdx.z;
     if (c >= W) return;
-    const int64_t fbase = (int64_t)b * H * W;
+    const int64_t n = (int64_t)H * W;
     const int r0 = ch * EDT_CH;
     unsigned word = 0, valid = 0;
 #pragma unroll 8
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(256) edt_bits_kernel(Fg fg, unsigned *__restri
         int r = r0 + j;
         if (r < H) {
             valid |= 1u << j;
-            if (fg(fbase + (int64_t)r * W + c)) word |= 1u << j;
+            if (fg(b, (int64_t)r * W + c, n)) word |= 1u << j;
         }
     }
     bits[((int64_t)b * nch + ch) * W + c] = word;
@@ -276,12 +277,14 @@ int pcseg_edt_sq_u8(const uint8_t *mask, int32_t *d2, int B, int H, int W, int c
     return edt_run(FgNzU8{mask}, EpiD2{d2, cap}, nullptr, B, H, W, workspace, workspace_bytes, (hipStream_t)stream, "edt_sq_u8");
 }
 
-int pcseg_edt_sq_lt_f32(const float *img, float threshold, int32_t *d2, uint8_t *mask_out, int B, int H, int W,
-                        void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
+int pcseg_edt_sq_lt_f32(const float *img, int64_t frame_stride, float threshold, int32_t *d2, uint8_t *mask_out, int B,
+                        int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
 {
     PCSEG_REQUIRE(img && d2 && workspace && check_shape(B, H, W), "bad arguments");
-    return edt_run(FgLtF32{img, threshold, mask_out}, EpiD2{d2, -1}, nullptr, B, H, W, workspace, workspace_bytes,
-                   (hipStream_t)stream, "edt_sq_lt_f32");
+    PCSEG_REQUIRE(frame_stride == 0 || frame_stride >= (int64_t)H * W, "frame_stride smaller than a frame");
+    if (frame_stride == 0) frame_stride = (int64_t)H * W;
+    return edt_run(FgLtF32{img, threshold, mask_out, frame_stride}, EpiD2{d2, -1}, nullptr, B, H, W, workspace,
+                   workspace_bytes, (hipStream_t)stream, "edt_sq_lt_f32");
 }
 
 int pcseg_dilate_disk_u8(const uint8_t *in, uint64_t value_bits, int radius, uint8_t *out, int B, int H, int W,

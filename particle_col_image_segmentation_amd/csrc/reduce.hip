@@ -183,52 +183,235 @@ __device__ __forceinline__ int block_exclusive_scan256(int v, int *total, int *w
 }
 
 __global__ void __launch_bounds__(256) merge_groups_kernel(const int *__restrict__ dl, const long long *__restrict__ stats,
-                                                            const uint8_t *__restrict__ select, const int *__restrict__ n_regions,
+                                                            const int *__restrict__ region_list, const int *__restrict__ n_list,
                                                             int *__restrict__ group_of, int *__restrict__ n_groups,
                                                             int *__restrict__ key_ws, int *__restrict__ first_ws,
-                                                            int *__restrict__ gid_ws, int H, int W, int cap)
+                                                            int *__restrict__ gid_ws, int H, int W, int cap, int list_cap)
 {
     __shared__ int wsum[4];
     const int b = blockIdx.x;
-    const int R = min(n_regions[b], cap);
+    const int R = min(n_list[b], list_cap);
     const int64_t n = (int64_t)H * W;
     const int *dlab = dl + (int64_t)b * n;
     const long long *st = stats + (int64_t)b * cap * 8;
-    const uint8_t *sel = select + (int64_t)b * cap;
-    int *key = key_ws + (int64_t)b * cap;
-    int *first = first_ws + (int64_t)b * (cap + 1);
-    int *gid = gid_ws + (int64_t)b * cap;
-    int *gof = group_of + (int64_t)b * cap;
+    const int *lst = region_list + (int64_t)b * list_cap;
+    int *key = key_ws + (int64_t)b * list_cap;
+    int *first = first_ws + (int64_t)b * (list_cap + 1);
+    int *gid = gid_ws + (int64_t)b * list_cap;
+    int *gof = group_of + (int64_t)b * list_cap;
     // keys (tiff_analysis.py:844-848): dilated label at (int(cy), int(cx)); exact with integer floor division
-    for (int r = threadIdx.x; r < R; r += 256) {
-        int k = 0;
-        if (sel[r]) {
+    for (int k = threadIdx.x; k < R; k += 256) {
+        int key_k = 0;
+        int r = lst[k];
+        if (r >= 0 && r < cap) {
             long long a = st[(int64_t)r * 8 + 0];
             if (a > 0) {
                 long long y = st[(int64_t)r * 8 + 1] / a, x = st[(int64_t)r * 8 + 2] / a;
-                if (y >= 0 && y < H && x >= 0 && x < W) k = dlab[y * W + x];
+                if (y >= 0 && y < H && x >= 0 && x < W) key_k = dlab[y * W + x];
             }
         }
-        if (k > cap) k = 0;  // cannot happen: a dilated image has no more components than regions
-        key[r] = k;
-        if (k > 0) first[k] = 0x7FFFFFFF;
+        key[k] = key_k;
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < R; r += 256)
-        if (key[r] > 0) atomicMin(&first[key[r]], r);
+    // dilated labels are arbitrary in 1..K (K may exceed the list length): remap through the list itself --
+    // first[] is indexed by the LIST POSITION of the first entry seen with that key, found by a tiny hash on key
+    // (open addressing over list_cap + 1 slots, keys stored in gid as scratch)
+    for (int k = threadIdx.x; k <= R; k += 256) first[k] = 0x7FFFFFFF;
+    for (int k = threadIdx.x; k < R; k += 256) gid[k] = 0;
+    __syncthreads();
+    // slot table: gid[slot] holds the key owning the slot (0 = free), first[slot] the smallest list position
+    for (int k = threadIdx.x; k < R; k += 256) {
+        int kk = key[k];
+        if (kk <= 0) continue;
+        unsigned slot = ((unsigned)kk * 2654435761u) % (unsigned)R;
+        for (;;) {
+            int owner = atomicCAS(&gid[slot], 0, kk);
+            if (owner == 0 || owner == kk) break;
+            slot = slot + 1 == (unsigned)R ? 0 : slot + 1;
+        }
+        atomicMin(&first[slot], k);
+        key[k] = -(int)slot - 1;  // remember the slot (negative marks "resolved")
+    }
     __syncthreads();
     int carry = 0;
+    // group ids in order of the first member: leaders are list positions k with first[slot(k)] == k
     for (int base = 0; base < R; base += 256) {
-        int r = base + threadIdx.x;
-        int leader = (r < R && key[r] > 0 && first[key[r]] == r) ? 1 : 0;
+        int k = base + threadIdx.x;
+        int leader = 0;
+        if (k < R && key[k] < 0) leader = first[-key[k] - 1] == k;
         int total;
         int ex = block_exclusive_scan256(leader, &total, wsum);
-        if (leader) gid[r] = carry + ex + 1;
+        if (leader) gof[k] = carry + ex + 1;
         carry += total;
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < R; r += 256) gof[r] = key[r] > 0 ? gid[first[key[r]]] : 0;
+    for (int k = threadIdx.x; k < R; k += 256) {
+        if (key[k] >= 0) gof[k] = 0;
+        else {
+            int f = first[-key[k] - 1];
+            if (f != k) gof[k] = gof[f];  // leaders were written before the barrier; members only read leaders
+        }
+    }
     if (threadIdx.x == 0) n_groups[b] = carry;
+}
+
+// ---- A3 tail + A4: the reference's per-region loop (tiff_analysis.py:754-781) and the region lists that
+// get_cell_clusters_from_distances builds (:794-796, 811, 820) for one frame per block.
+constexpr int CLS_T = 4;  // cell-type slots (the reference has 3: CELL_TYPES)
+
+struct ClassTables {
+    uint8_t slot[256];      // class value -> cell-type slot, 255 = not a cell type
+    uint8_t particle[256];  // class value is "Particle"
+    int min_cell[CLS_T];
+    int min_cluster[CLS_T];
+    int n_slots;
+};
+
+// numpy's float64 floor_divide (npy_divmod): fmod-based, exact for the rounded divisor
+__device__ __forceinline__ double npy_floor_divide(double a, double b)
+{
+    double mod = fmod(a, b);
+    if (!(b == b) || !(mod == mod)) return mod;  // NaN
+    double div = (a - mod) / b;
+    if (mod != 0.0 && ((b < 0) != (mod < 0))) div -= 1.0;
+    double fl;
+    if (div != 0.0) {
+        fl = floor(div);
+        if (div - fl > 0.5) fl += 1.0;
+    } else fl = 0.0;
+    return fl;
+}
+
+__global__ void __launch_bounds__(256) classify_regions_kernel(const long long *__restrict__ stats, const uint8_t *__restrict__ cls_out,
+                                                                const int *__restrict__ counts, ClassTables tab,
+                                                                uint8_t *__restrict__ kind, uint8_t *__restrict__ slot_of,
+                                                                int *__restrict__ cells, long long *__restrict__ particle_area,
+                                                                long long *__restrict__ type_stats /*(B,CLS_T,4)*/,
+                                                                int *__restrict__ region_list /*(B,CLS_T+1,cap)*/,
+                                                                int *__restrict__ n_list /*(B,CLS_T+1)*/, int *__restrict__ nan_flag,
+                                                                int cap)
+{
+    __shared__ unsigned long long s_particle;
+    __shared__ int s_first[CLS_T], s_ncell[CLS_T], s_nclu[CLS_T], s_base[CLS_T];
+    __shared__ unsigned long long s_sumcell[CLS_T];
+    __shared__ int wsum[4];
+    __shared__ int s_nan;
+    const int b = blockIdx.x;
+    const int R = min(counts[b], cap);
+    const long long *st = stats + (int64_t)b * cap * 8;
+    const uint8_t *co = cls_out + (int64_t)b * cap;
+    uint8_t *kd = kind + (int64_t)b * cap, *so = slot_of + (int64_t)b * cap;
+    int *cl = cells + (int64_t)b * cap;
+    if (threadIdx.x < CLS_T) {
+        s_first[threadIdx.x] = 0x7FFFFFFF; s_ncell[threadIdx.x] = 0; s_nclu[threadIdx.x] = 0; s_sumcell[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) { s_particle = 0; s_nan = 0; }
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += 256) {
+        int c = co[r];
+        long long area = st[(int64_t)r * 8];
+        int slot = tab.slot[c];
+        int k = 0;
+        if (tab.particle[c]) atomicAdd(&s_particle, (unsigned long long)area);
+        if (slot != 255) {
+            atomicMin(&s_first[slot], r);
+            if (area >= tab.min_cell[slot] && area < tab.min_cluster[slot]) {
+                k = 1;
+                atomicAdd(&s_ncell[slot], 1);
+                atomicAdd(&s_sumcell[slot], (unsigned long long)area);
+            } else if (area >= tab.min_cluster[slot]) {
+                k = 2;
+                atomicAdd(&s_nclu[slot], 1);
+            }
+        }
+        kd[r] = (uint8_t)k;
+        so[r] = (uint8_t)slot;
+        cl[r] = k == 1 ? 1 : 0;
+    }
+    __syncthreads();
+    // cluster.cells = int(area // mean(cell areas))   (:776-781)
+    for (int r = threadIdx.x; r < R; r += 256) {
+        if (kd[r] != 2) continue;
+        int slot = so[r];
+        if (s_ncell[slot] == 0) { cl[r] = -1; s_nan = 1; continue; }  // the reference raises ValueError here
+        double avg = (double)s_sumcell[slot] / (double)s_ncell[slot];
+        cl[r] = (int)npy_floor_divide((double)st[(int64_t)r * 8], avg);
+    }
+    // combined-list bases: types in the order of their first region (dict insertion order of the reference)
+    if (threadIdx.x < CLS_T) {
+        int me = threadIdx.x, base = 0;
+        for (int t = 0; t < CLS_T; ++t)
+            if (t != me && s_first[t] < s_first[me]) base += s_ncell[t] + s_nclu[t];
+        s_base[me] = base;
+    }
+    __syncthreads();
+    int *lists = region_list + (int64_t)b * (CLS_T + 1) * cap;
+    for (int slot = 0; slot < tab.n_slots; ++slot) {
+        int carry_cell = 0, carry_clu = 0;
+        for (int base = 0; base < R; base += 256) {
+            int r = base + threadIdx.x;
+            int is_cell = (r < R && so[r] == slot && kd[r] == 1) ? 1 : 0;
+            int is_clu = (r < R && so[r] == slot && kd[r] == 2) ? 1 : 0;
+            int tot_cell, tot_clu;
+            int ex_cell = block_exclusive_scan256(is_cell, &tot_cell, wsum);
+            int ex_clu = block_exclusive_scan256(is_clu, &tot_clu, wsum);
+            if (is_cell) {
+                int pos = carry_cell + ex_cell;
+                lists[(int64_t)slot * cap + pos] = r;
+                lists[(int64_t)CLS_T * cap + s_base[slot] + pos] = r;
+            }
+            if (is_clu) {
+                int pos = s_ncell[slot] + carry_clu + ex_clu;
+                lists[(int64_t)slot * cap + pos] = r;
+                lists[(int64_t)CLS_T * cap + s_base[slot] + pos] = r;
+            }
+            carry_cell += tot_cell;
+            carry_clu += tot_clu;
+        }
+    }
+    if (threadIdx.x < CLS_T) {
+        int t = threadIdx.x;
+        n_list[b * (CLS_T + 1) + t] = s_ncell[t] + s_nclu[t];
+        long long *ts = type_stats + ((int64_t)b * CLS_T + t) * 4;
+        ts[0] = s_ncell[t]; ts[1] = s_nclu[t]; ts[2] = (long long)s_sumcell[t]; ts[3] = s_first[t];
+    }
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int t = 0; t < CLS_T; ++t) tot += s_ncell[t] + s_nclu[t];
+        n_list[b * (CLS_T + 1) + CLS_T] = tot;
+        particle_area[b] = (long long)s_particle;
+        nan_flag[b] = s_nan;
+    }
+}
+
+// group table of pcseg_merge_groups: (B, list_cap, 8) = area, sum_row, sum_col, bbox(4), members
+__global__ void __launch_bounds__(256) group_reduce_kernel(const long long *__restrict__ stats, const int *__restrict__ region_list,
+                                                            const int *__restrict__ n_list, const int *__restrict__ group_of,
+                                                            const int *__restrict__ n_groups, long long *__restrict__ gstats,
+                                                            int cap, int list_cap, int H, int W)
+{
+    const int b = blockIdx.x;
+    const int R = min(n_list[b], list_cap), G = n_groups[b];
+    long long *gs = gstats + (int64_t)b * list_cap * 8;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        long long *t = gs + (int64_t)g * 8;
+        t[0] = 0; t[1] = 0; t[2] = 0; t[3] = H; t[4] = W; t[5] = 0; t[6] = 0; t[7] = 0;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < R; k += 256) {
+        int g = group_of[(int64_t)b * list_cap + k];
+        if (g <= 0) continue;
+        const long long *s = stats + ((int64_t)b * cap + region_list[(int64_t)b * list_cap + k]) * 8;
+        long long *t = gs + (int64_t)(g - 1) * 8;
+        atomicAdd((unsigned long long *)&t[0], (unsigned long long)s[0]);
+        atomicAdd((unsigned long long *)&t[1], (unsigned long long)s[1]);
+        atomicAdd((unsigned long long *)&t[2], (unsigned long long)s[2]);
+        atomicMin(&t[3], s[3]);
+        atomicMin(&t[4], s[4]);
+        atomicMax(&t[5], s[5]);
+        atomicMax(&t[6], s[6]);
+        atomicAdd((unsigned long long *)&t[7], 1ull);
+    }
 }
 
 }  // namespace pcseg
@@ -275,29 +458,65 @@ int pcseg_region_reduce(const int32_t *labels, const uint8_t *cls, const float *
     return pcseg_region_reduce_n(labels, nullptr, cls, planes, C, B, H, W, cap, stats, cls_out, sums, overflow, stream);
 }
 
-size_t pcseg_merge_groups_workspace_bytes(int B, int cap)
+size_t pcseg_merge_groups_workspace_bytes(int B, int list_cap)
 {
-    if (B < 1 || cap < 1) return 0;
-    return align_up(sizeof(int) * (size_t)B * cap) * 2 + align_up(sizeof(int) * (size_t)B * (cap + 1));
+    if (B < 1 || list_cap < 1) return 0;
+    return align_up(sizeof(int) * (size_t)B * list_cap) * 2 + align_up(sizeof(int) * (size_t)B * (list_cap + 1));
 }
 
-int pcseg_merge_groups(const int32_t *dilated_labels, const int64_t *stats, const uint8_t *select, const int32_t *n_regions,
-                       int32_t *group_of, int32_t *n_groups, int B, int H, int W, int cap, void *workspace,
+int pcseg_merge_groups(const int32_t *dilated_labels, const int64_t *stats, const int32_t *region_list, const int32_t *n_list,
+                       int32_t *group_of, int32_t *n_groups, int B, int H, int W, int cap, int list_cap, void *workspace,
                        size_t workspace_bytes, pcseg_stream_t stream)
 {
-    PCSEG_REQUIRE(dilated_labels && stats && select && n_regions && group_of && n_groups && workspace && cap >= 1 &&
-                      check_shape(B, H, W),
+    PCSEG_REQUIRE(dilated_labels && stats && region_list && n_list && group_of && n_groups && workspace && cap >= 1 &&
+                      list_cap >= 1 && check_shape(B, H, W),
                   "bad arguments");
     Carver cv(workspace, workspace_bytes);
-    int *key = cv.take<int>((size_t)B * cap);
-    int *gid = cv.take<int>((size_t)B * cap);
-    int *first = cv.take<int>((size_t)B * (cap + 1));
+    int *key = cv.take<int>((size_t)B * list_cap);
+    int *gid = cv.take<int>((size_t)B * list_cap);
+    int *first = cv.take<int>((size_t)B * (list_cap + 1));
     if (!cv.ok()) {
         set_error("merge_groups: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
     }
     hipLaunchKernelGGL(merge_groups_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dilated_labels,
-                       (const long long *)stats, select, n_regions, group_of, n_groups, key, first, gid, H, W, cap);
+                       (const long long *)stats, region_list, n_list, group_of, n_groups, key, first, gid, H, W, cap, list_cap);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+int pcseg_classify_regions(const int64_t *stats, const uint8_t *cls_out, const int32_t *counts, const uint8_t *class_slot,
+                           const uint8_t *class_particle, const int32_t *min_cell, const int32_t *min_cluster, int n_slots,
+                           uint8_t *kind, uint8_t *slot_of, int32_t *cells, int64_t *particle_area, int64_t *type_stats,
+                           int32_t *region_list, int32_t *n_list, int32_t *nan_flag, int B, int cap, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(stats && cls_out && counts && class_slot && class_particle && min_cell && min_cluster && kind && slot_of &&
+                      cells && particle_area && type_stats && region_list && n_list && nan_flag && B >= 1 && cap >= 1 &&
+                      n_slots >= 0 && n_slots <= CLS_T,
+                  "bad arguments (class tables are HOST arrays: slot[256], particle[256], min_cell[n], min_cluster[n])");
+    ClassTables tab;
+    memcpy(tab.slot, class_slot, 256);
+    memcpy(tab.particle, class_particle, 256);
+    for (int t = 0; t < CLS_T; ++t) {
+        tab.min_cell[t] = t < n_slots ? min_cell[t] : 0x7FFFFFFF;
+        tab.min_cluster[t] = t < n_slots ? min_cluster[t] : 0x7FFFFFFF;
+    }
+    tab.n_slots = n_slots;
+    hipLaunchKernelGGL(classify_regions_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)stats, cls_out,
+                       counts, tab, kind, slot_of, cells, (long long *)particle_area, (long long *)type_stats, region_list, n_list,
+                       nan_flag, cap);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+int pcseg_group_reduce(const int64_t *stats, const int32_t *region_list, const int32_t *n_list, const int32_t *group_of,
+                       const int32_t *n_groups, int64_t *group_stats, int B, int H, int W, int cap, int list_cap,
+                       pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(stats && region_list && n_list && group_of && n_groups && group_stats && B >= 1 && cap >= 1 && list_cap >= 1,
+                  "bad arguments");
+    hipLaunchKernelGGL(group_reduce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)stats, region_list,
+                       n_list, group_of, n_groups, (long long *)group_stats, cap, list_cap, H, W);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

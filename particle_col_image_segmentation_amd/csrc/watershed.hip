@@ -34,14 +34,15 @@ __device__ __forceinline__ unsigned ws_key(float f)
     return u == WS_INF ? WS_INF - 1 : u;
 }
 
-__global__ void __launch_bounds__(256) ws_init_kernel(const float *__restrict__ img, const int *__restrict__ markers,
-                                                       const uint8_t *__restrict__ mask, unsigned *__restrict__ val,
-                                                       unsigned *__restrict__ L, int *__restrict__ out, int64_t total)
+__global__ void __launch_bounds__(256) ws_init_kernel(const float *__restrict__ img, int64_t frame_stride,
+                                                       const int *__restrict__ markers, const uint8_t *__restrict__ mask,
+                                                       unsigned *__restrict__ val, unsigned *__restrict__ L,
+                                                       int *__restrict__ out, int64_t n, int64_t total)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     bool m = mask[i] != 0;
-    unsigned v = m ? ws_key(img[i]) : WS_INF;
+    unsigned v = m ? ws_key(img[(i / n) * frame_stride + (i % n)]) : WS_INF;
     int mk = m ? markers[i] : 0;
     val[i] = v;
     L[i] = mk != 0 ? v : WS_INF;
@@ -292,10 +293,13 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
            align_up(n * 8) + align_up(n * 4);
 }
 
-int pcseg_watershed4_f32(const float *img, const int32_t *markers, const uint8_t *mask, int32_t *out, int32_t *tie_flags,
-                         int B, int H, int W, int mode, void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
+int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *markers, const uint8_t *mask, int32_t *out,
+                         int32_t *tie_flags, int B, int H, int W, int mode, void *workspace, size_t workspace_bytes,
+                         pcseg_stream_t stream)
 {
     PCSEG_REQUIRE(img && markers && mask && out && workspace && check_shape(B, H, W) && mode >= 0 && mode <= 2, "bad arguments");
+    PCSEG_REQUIRE(frame_stride == 0 || frame_stride >= (int64_t)H * W, "frame_stride smaller than a frame");
+    if (frame_stride == 0) frame_stride = (int64_t)H * W;
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)B * H * W;
     const int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
@@ -313,8 +317,8 @@ int pcseg_watershed4_f32(const float *img, const int32_t *markers, const uint8_t
         set_error("watershed: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(ws_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, markers, mask, val, L, out,
-                       (int64_t)n);
+    hipLaunchKernelGGL(ws_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, frame_stride, markers, mask, val, L,
+                       out, (int64_t)H * W, (int64_t)n);
     PCSEG_CHECK_LAUNCH();
     if (mode == 1) {
         hipLaunchKernelGGL(ws_set_flags_kernel, dim3((B + 63) / 64), dim3(64), 0, s, flags, B, 1);

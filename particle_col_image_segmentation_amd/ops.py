@@ -151,17 +151,27 @@ def edt_sq(mask, cap=-1):
     return d2
 
 
+def _plane_view(img):
+    """(B,H,W) float32 view whose frames may be strided (a plane of a (B,C,H,W) stack): (tensor, frame stride)."""
+    if not isinstance(img, torch.Tensor) or not img.is_cuda or img.dtype != torch.float32 or img.dim() != 3:
+        raise TypeError("expected a (B,H,W) float32 CUDA tensor")
+    B, H, W = img.shape
+    if img.stride(2) == 1 and img.stride(1) == W and (B == 1 or img.stride(0) >= H * W):
+        return img, (img.stride(0) if B > 1 else H * W)
+    return img.contiguous(), H * W
+
+
 def edt_sq_lt(img, threshold, want_mask=True):
-    """fused threshold + squared EDT (refine_boundaries.py:44-45, 60)."""
-    img = _req(img, torch.float32, 3)
+    """fused threshold + squared EDT (refine_boundaries.py:44-45, 60); img may be a plane view of a stack."""
+    img, fstride = _plane_view(img)
     B, H, W = img.shape
     lib = _lib.load()
     d2 = torch.empty((B, H, W), dtype=torch.int32, device=img.device)
     mask = torch.empty((B, H, W), dtype=torch.uint8, device=img.device) if want_mask else None
     nbytes = lib.pcseg_edt_workspace_bytes(B, H, W)
     ws = _ws(nbytes, img.device)
-    _lib.check(lib.pcseg_edt_sq_lt_f32(_ptr(img), float(threshold), _ptr(d2), _ptr(mask), B, H, W, _ptr(ws), nbytes,
-                                       _stream()), "edt_sq_lt")
+    _lib.check(lib.pcseg_edt_sq_lt_f32(_ptr(img), fstride, float(threshold), _ptr(d2), _ptr(mask), B, H, W, _ptr(ws),
+                                       nbytes, _stream()), "edt_sq_lt")
     return d2, mask
 
 
@@ -226,7 +236,7 @@ def watershed(img, markers, mask, mode=0):
 
     Returns (labels int32, tie_flags int32 (B,)): tie_flags[b] = 1 where the parallel flood could not be
     proven exact (mode 0 re-runs those frames with the exact sequential flood)."""
-    img = _req(img, torch.float32, 3)
+    img, fstride = _plane_view(img)
     markers = _req(markers, torch.int32, 3)
     mask = _req(mask, torch.uint8, 3)
     B, H, W = img.shape
@@ -235,27 +245,99 @@ def watershed(img, markers, mask, mode=0):
     flags = torch.zeros((B,), dtype=torch.int32, device=img.device)
     nbytes = lib.pcseg_watershed_workspace_bytes(B, H, W)
     ws = _ws(nbytes, img.device)
-    _lib.check(lib.pcseg_watershed4_f32(_ptr(img), _ptr(markers), _ptr(mask), _ptr(out), _ptr(flags), B, H, W, int(mode),
+    _lib.check(lib.pcseg_watershed4_f32(_ptr(img), fstride, _ptr(markers), _ptr(mask), _ptr(out), _ptr(flags), B, H, W, int(mode),
                                         _ptr(ws), nbytes, _stream()), "watershed")
     return out, flags
 
 
-def merge_groups(dilated_labels, stats, select, n_regions):
-    """get_merged_regions grouping (tiff_analysis.py:843-878): group id per region, 0 = dropped."""
+def merge_groups(dilated_labels, stats, region_list, n_list):
+    """get_merged_regions grouping (tiff_analysis.py:843-878): group id per list entry, 0 = dropped."""
     dl = _req(dilated_labels, torch.int32, 3)
     stats = _req(stats, torch.int64, 3)
-    select = _req(select, torch.uint8, 2)
-    n_regions = _req(n_regions, torch.int32, 1)
+    region_list = _req(region_list, torch.int32, 2)
+    n_list = _req(n_list, torch.int32, 1)
     B, H, W = dl.shape
     cap = stats.shape[1]
+    list_cap = region_list.shape[1]
     lib = _lib.load()
-    group_of = torch.zeros((B, cap), dtype=torch.int32, device=dl.device)
+    group_of = torch.zeros((B, list_cap), dtype=torch.int32, device=dl.device)
     n_groups = torch.zeros((B,), dtype=torch.int32, device=dl.device)
-    nbytes = lib.pcseg_merge_groups_workspace_bytes(B, cap)
+    nbytes = lib.pcseg_merge_groups_workspace_bytes(B, list_cap)
     ws = _ws(nbytes, dl.device)
-    _lib.check(lib.pcseg_merge_groups(_ptr(dl), _ptr(stats), _ptr(select), _ptr(n_regions), _ptr(group_of), _ptr(n_groups),
-                                      B, H, W, cap, _ptr(ws), nbytes, _stream()), "merge_groups")
+    _lib.check(lib.pcseg_merge_groups(_ptr(dl), _ptr(stats), _ptr(region_list), _ptr(n_list), _ptr(group_of),
+                                      _ptr(n_groups), B, H, W, cap, list_cap, _ptr(ws), nbytes, _stream()), "merge_groups")
     return group_of, n_groups
+
+
+def group_reduce(stats, region_list, n_list, group_of, n_groups, H, W):
+    """member sums of merged groups (tiff_analysis.py:855-872): int64 (B, list_cap, 8)."""
+    B, cap = stats.shape[0], stats.shape[1]
+    list_cap = region_list.shape[1]
+    lib = _lib.load()
+    gstats = torch.zeros((B, list_cap, 8), dtype=torch.int64, device=stats.device)
+    _lib.check(lib.pcseg_group_reduce(_ptr(stats), _ptr(region_list), _ptr(n_list), _ptr(group_of), _ptr(n_groups),
+                                      _ptr(gstats), B, H, W, cap, list_cap, _stream()), "group_reduce")
+    return gstats
+
+
+class ClassTables:
+    """Host-side class tables of pcseg_classify_regions built from the reference's ``cell_types`` dict and its
+    MIN_CELL_AREA / MIN_CLUSTER_AREA constants (tiff_analysis.py:54-60, 754-773)."""
+
+    def __init__(self, cell_types, cell_type_names, min_cell_area, min_cluster_area):
+        import numpy as np
+        self.slot_names = []
+        slot = np.full(256, 255, np.uint8)
+        particle = np.zeros(256, np.uint8)
+        for val, name in cell_types.items():
+            if name in cell_type_names:
+                if name not in self.slot_names:
+                    self.slot_names.append(name)
+                slot[val] = self.slot_names.index(name)
+            elif name == "Particle":
+                particle[val] = 1
+        if len(self.slot_names) > 4:
+            raise ValueError("at most 4 cell types")
+        self.slot = slot
+        self.particle = particle
+        self.min_cell = np.array([min_cell_area[n] for n in self.slot_names] or [0], np.int32)
+        self.min_cluster = np.array([min_cluster_area[n] for n in self.slot_names] or [0], np.int32)
+        # class value that get_cell_clusters_from_distances looks up per type: the FIRST key with that name (:806-810)
+        self.slot_value = []
+        for n in self.slot_names:
+            self.slot_value.append([v for v, t in cell_types.items() if t == n][0])
+        self.cell_values = [v for v, t in cell_types.items() if t in cell_type_names]
+        self.particle_value = None
+        for v, t in cell_types.items():
+            if t == "Particle":
+                self.particle_value = v
+
+
+def classify_regions(stats, cls_out, counts, tables):
+    """per-region loop of get_cell_positions_and_areas + region lists (tiff_analysis.py:754-781, 794-796)."""
+    stats = _req(stats, torch.int64, 3)
+    cls_out = _req(cls_out, torch.uint8, 2)
+    counts = _req(counts, torch.int32, 1)
+    B, cap = stats.shape[0], stats.shape[1]
+    dev = stats.device
+    out = {
+        "kind": torch.zeros((B, cap), dtype=torch.uint8, device=dev),
+        "slot_of": torch.full((B, cap), 255, dtype=torch.uint8, device=dev),
+        "cells": torch.zeros((B, cap), dtype=torch.int32, device=dev),
+        "particle_area": torch.zeros((B,), dtype=torch.int64, device=dev),
+        "type_stats": torch.zeros((B, 4, 4), dtype=torch.int64, device=dev),
+        "region_list": torch.full((B, 5, cap), -1, dtype=torch.int32, device=dev),
+        "n_list": torch.zeros((B, 5), dtype=torch.int32, device=dev),
+        "nan_flag": torch.zeros((B,), dtype=torch.int32, device=dev),
+    }
+    lib = _lib.load()
+    hp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    _lib.check(lib.pcseg_classify_regions(_ptr(stats), _ptr(cls_out), _ptr(counts), hp(tables.slot), hp(tables.particle),
+                                          hp(tables.min_cell), hp(tables.min_cluster), len(tables.slot_names),
+                                          _ptr(out["kind"]), _ptr(out["slot_of"]), _ptr(out["cells"]),
+                                          _ptr(out["particle_area"]), _ptr(out["type_stats"]), _ptr(out["region_list"]),
+                                          _ptr(out["n_list"]), _ptr(out["nan_flag"]), B, cap, _stream()), "classify_regions")
+    return out
 
 
 def remove_overlapping(dapi, other, threshold):

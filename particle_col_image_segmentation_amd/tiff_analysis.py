@@ -1,0 +1,529 @@
+"""Drop-in for the hot-path functions of the reference's ``tiff_analysis.py``.
+
+Same names, positional arguments, return shapes and error behaviour as
+ssilverman16/particle_col_image_segmentation ``tiff_analysis.py`` (cited per
+function); the pixel work runs in the HIP kernels of ``libpcseg.so`` through
+``ops`` -- there is no CPU path.  Images go in and come back as numpy arrays
+(torch CUDA tensors are accepted and then returned as tensors).
+
+Not reproduced on purpose (out of scope, SURVEY.md section 2: C9-C11, C13):
+matplotlib plotting and the ``main()`` folder walk.
+"""
+import csv
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+
+# --- constants: tiff_analysis.py:47-82 (they are the reference's whole flag system)
+BASE_TYPE_MAP = {1: "3D05", 2: "6B07", 3: "C3M10", 4: "Particle", 5: "Background"}
+CELL_TYPES = ["3D05", "6B07", "C3M10"]
+CHANNELS = ["RFP", "DAPI", "GFP"]
+CHANNEL_MAP = {"RFP": "3D05", "DAPI": "6B07", "GFP": "C3M10"}
+STRAIN_MAP = {"3D05": "RFP", "6B07": "DAPI", "C3M10": "GFP"}
+MIN_CELL_AREA = {"3D05": 20, "6B07": 20, "C3M10": 20}
+MIN_CLUSTER_AREA = {"3D05": 200, "6B07": 200, "C3M10": 370}
+DENOISE_SIZE = 5
+DILATION_RADIUS = 20
+DISTANCE_THRESHOLD = 2
+CELL_CLUSTER_DISTANCE_THRESHOLD = 5
+DAPI_RFP_OVERLAP_THRESHOLD = 0.1
+PX_TO_UM_CONV = 9.95
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("particle_col_image_segmentation_amd needs a ROCm GPU: the HIP path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_dev_u8(a):
+    """(H, W) integer / bool image -> (1, H, W) uint8 CUDA tensor, plus 'caller passed a tensor'."""
+    if isinstance(a, torch.Tensor):
+        t = a
+        was_tensor = True
+    else:
+        arr = np.asarray(a)
+        if arr.dtype != np.uint8 and arr.dtype != bool and arr.size and (arr.min() < 0 or arr.max() > 255):
+            raise ValueError("class maps must hold values 0..255")
+        t = torch.from_numpy(np.ascontiguousarray(arr.astype(np.uint8, copy=False)))
+        was_tensor = False
+    if t.dim() != 2:
+        raise ValueError("expected a 2-D image, got shape %s" % (tuple(t.shape),))
+    return t.to(device=_device(), dtype=torch.uint8).contiguous()[None], was_tensor
+
+
+def _back(t, was_tensor, dtype=None):
+    if was_tensor:
+        return t
+    a = t.cpu().numpy()
+    return a.astype(dtype) if dtype is not None else a
+
+
+class _LabelImage:
+    """Device label image of one frame with a lazily fetched host copy (for Region.coords)."""
+
+    def __init__(self, dev_labels):
+        self.dev = dev_labels
+        self._host = None
+
+    @property
+    def host(self):
+        if self._host is None:
+            self._host = self.dev.cpu().numpy()
+        return self._host
+
+
+class Region:
+    """Duck type of skimage RegionProperties restricted to what the reference touches:
+    .label (:270), .area (:275, 769-781, 855, 1031, 1055), ["area"] (:1033), .centroid (:406, 844, 1054),
+    .bbox (:860-863, 912), .coords[0] (:1042), dynamically added .cells (:781, 1029, 1063)."""
+
+    __slots__ = ("label", "area", "centroid", "bbox", "first", "sum_row", "sum_col", "cells", "_im")
+
+    def __init__(self, label_id, row, width, label_image=None):
+        self.label = int(label_id)
+        # numpy scalars on purpose: the reference's CSV writers call round() on them, and numpy's round
+        # (x*10^n -> rint -> /10^n) differs from Python's float round on decimal ties (tiff_analysis.py:1057)
+        self.area = np.int64(row[0])
+        self.sum_row = int(row[1])
+        self.sum_col = int(row[2])
+        # np.mean of integer coordinates = float64(sum) / count (skimage/measure/_regionprops.py:296-297)
+        self.centroid = (np.float64(row[1]) / np.float64(row[0]), np.float64(row[2]) / np.float64(row[0]))
+        self.bbox = (int(row[3]), int(row[4]), int(row[5]), int(row[6]))
+        self.first = (int(row[7]) // width, int(row[7]) % width)
+        self._im = label_image
+
+    @property
+    def coords(self):
+        if self._im is None:
+            return np.array([self.first])
+        return np.argwhere(self._im.host == self.label)
+
+    def __getitem__(self, key):
+        return getattr(self, key)
+
+
+def median_filter(ds_arr, size=DENOISE_SIZE):
+    """scipy.ndimage.median_filter(ds_arr, size=5) as called at tiff_analysis.py:122, 643."""
+    if size != 5:
+        raise ValueError("only size=5 (DENOISE_SIZE) is built")
+    t, was = _to_dev_u8(ds_arr)
+    return _back(ops.median5(t)[0], was)
+
+
+def label(image):
+    """skimage.measure.label(image) as called at tiff_analysis.py:743 (int) and :260, :829 (bool)."""
+    is_bool = (image.dtype == torch.bool) if isinstance(image, torch.Tensor) else (np.asarray(image).dtype == bool)
+    t, was = _to_dev_u8(image)
+    lab, _ = (ops.label_bool8 if is_bool else ops.label_equal8)(t)
+    return _back(lab[0], was, np.int64 if not is_bool else np.int32)
+
+
+def _regions_of(z_dev):
+    """label + regionprops of one frame on the device; returns (regions, label image holder, stats tensor)."""
+    labels, counts = ops.label_equal8(z_dev)
+    n = int(counts[0].item())
+    stats, cls_out, _, _ = ops.region_reduce(labels, counts, cls=z_dev, cap=max(n, 1))
+    holder = _LabelImage(labels[0])
+    st = stats[0, :n].cpu().numpy()
+    cl = cls_out[0, :n].cpu().numpy()
+    width = z_dev.shape[2]
+    regions = [Region(i + 1, st[i], width, holder) for i in range(n)]
+    return regions, cl, holder, stats
+
+
+def regionprops(label_im):
+    """skimage.measure.regionprops(label_im) reduced to the fields the reference reads (tiff_analysis.py:746)."""
+    if isinstance(label_im, torch.Tensor):
+        lab = label_im.to(device=_device(), dtype=torch.int32).contiguous()[None]
+    else:
+        lab = torch.from_numpy(np.ascontiguousarray(np.asarray(label_im).astype(np.int32)))[None].to(_device())
+    n = int(lab.max().item()) if lab.numel() else 0
+    stats, _, _, _ = ops.region_reduce(lab, cap=max(n, 1))
+    st = stats[0, :n].cpu().numpy()
+    holder = _LabelImage(lab[0])
+    return [Region(i + 1, st[i], lab.shape[2], holder) for i in range(n) if st[i][0] > 0]
+
+
+def get_type(region, data):
+    """tiff_analysis.py:1041-1044."""
+    point = getattr(region, "first", None)
+    if point is None:
+        point = region.coords[0]
+    return data[point[0], point[1]]
+
+
+def get_cell_positions_and_areas(z_slice, cell_types, merged=False):
+    """tiff_analysis.py:742-789.  Returns (cell_pos, cell_clusters, particle_area, merged_clusters)."""
+    z_dev, _ = _to_dev_u8(z_slice)
+    regions, classes, _, stats = _regions_of(z_dev)
+    cell_pos, cell_clusters, particle_area = {}, {}, 0
+    for region, region_type in zip(regions, classes):
+        cell_type = cell_types[int(region_type)]  # KeyError for an unmapped class value, like the reference (:756)
+        if cell_type not in CELL_TYPES:
+            if cell_type == "Particle":
+                particle_area += region.area
+            continue
+        min_cell_area = MIN_CELL_AREA[cell_type]
+        min_cluster_area = MIN_CLUSTER_AREA[cell_type]
+        if cell_type not in cell_pos:
+            cell_pos[cell_type] = []
+            cell_clusters[cell_type] = []
+        if min_cell_area <= region.area < min_cluster_area:
+            cell_pos[cell_type].append(region)
+        if region.area >= min_cluster_area:
+            cell_clusters[cell_type].append(region)
+    cell_area_averages = {}
+    for cell_type, cell_array in cell_pos.items():
+        with np.errstate(all="ignore"):
+            cell_area_averages[cell_type] = (np.average([np.int64(c.area) for c in cell_array])
+                                             if cell_array else np.float64("nan"))
+    for cell_type, cluster_array in cell_clusters.items():
+        for cluster in cluster_array:
+            # int(NaN) raises ValueError exactly like the reference when a type has clusters but no single cell
+            cluster.cells = int(np.int64(cluster.area) // cell_area_averages[cell_type])
+    if merged:
+        merged_clusters, _ = _clusters_from_distances(z_dev, stats, cell_pos, cell_clusters, cell_types, False)
+    else:
+        merged_clusters = {}
+    return cell_pos, cell_clusters, particle_area, merged_clusters
+
+
+def _group_regions(dl_dev, stats_dev, og_cell_regions):
+    """device grouping (pcseg_merge_groups) + host assembly of the reference's merged-region dicts (:850-872)."""
+    n = len(og_cell_regions)
+    dev = dl_dev.device
+    lst = torch.full((1, max(n, 1)), -1, dtype=torch.int32)
+    if n:
+        lst[0, :n] = torch.tensor([r.label - 1 for r in og_cell_regions], dtype=torch.int32)
+    group_of, n_groups = ops.merge_groups(dl_dev, stats_dev, lst.to(dev), torch.tensor([n], dtype=torch.int32, device=dev))
+    gof = group_of[0, :n].cpu().numpy()
+    groups = [[] for _ in range(int(n_groups[0].item()))]
+    for r, g in zip(og_cell_regions, gof):
+        if g > 0:
+            groups[g - 1].append(r)
+    merged_regions = []
+    for touching in groups:
+        merged_regions.append({
+            "area": sum(r.area for r in touching),
+            "centroid": np.average([r.centroid for r in touching], axis=0, weights=[r.area for r in touching]),
+            "regions": touching,
+            "bbox": (min(r.bbox[0] for r in touching), min(r.bbox[1] for r in touching),
+                     max(r.bbox[2] for r in touching), max(r.bbox[3] for r in touching)),
+        })
+    return merged_regions, gof
+
+
+def _stats_from_regions(regions, dev):
+    cap = max([r.label for r in regions], default=1)
+    st = np.zeros((1, cap, 8), np.int64)
+    for r in regions:
+        st[0, r.label - 1, :3] = (r.area, r.sum_row, r.sum_col)
+    return torch.from_numpy(st).to(dev)
+
+
+def _merged_regions_dev(z_dev, value_bits, stats_dev, og_cell_regions, want_image):
+    dil = ops.dilate_disk(z_dev, value_bits, CELL_CLUSTER_DISTANCE_THRESHOLD // 2)
+    dl, dl_counts = ops.label_bool8(dil)
+    merged_regions, _ = _group_regions(dl, stats_dev, og_cell_regions)
+    merged_image = None
+    if want_image:
+        # union of the dilated components that hold a listed centroid, holes filled (:876-880)
+        K = int(dl_counts[0].item())
+        keep = torch.zeros((K + 1,), dtype=torch.uint8, device=dl.device)
+        H, W = dl.shape[1:]
+        ys = torch.tensor([min(max(int(r.centroid[0]), 0), H - 1) for r in og_cell_regions], dtype=torch.long, device=dl.device)
+        xs = torch.tensor([min(max(int(r.centroid[1]), 0), W - 1) for r in og_cell_regions], dtype=torch.long, device=dl.device)
+        if len(og_cell_regions):
+            keep[dl[0, ys, xs].long()] = 1
+        keep[0] = 0
+        sel = keep[dl.long()]
+        merged_image = ops.fill_holes(sel)[0].bool()
+    return merged_regions, merged_image
+
+
+def _clusters_from_distances(z_dev, stats_dev, cell_pos, cell_clusters, cell_types, want_images):
+    combined = {}
+    # the reference iterates a set of the type names (hash-randomised order, :794); insertion order here
+    for key in list(cell_pos) + [k for k in cell_clusters if k not in cell_pos]:
+        combined[key] = cell_pos.get(key, []) + cell_clusters.get(key, [])
+    merged_regions, merged_images, img_vals, combined_regions = {}, {}, [], []
+    for cell_type, cell_regions in combined.items():
+        cell_img_val = 0
+        for cell_val, cell_temp_type in cell_types.items():
+            if cell_temp_type == cell_type:
+                cell_img_val = cell_val
+                break
+        img_vals.append(cell_img_val)
+        combined_regions.extend(cell_regions)
+        merged_regions[cell_type], merged_images[cell_type] = _merged_regions_dev(
+            z_dev, 1 << cell_img_val, stats_dev, cell_regions, want_images)
+    bits = 0
+    for v in img_vals:
+        bits |= 1 << v
+    merged_regions["combined"], merged_images["combined"] = _merged_regions_dev(
+        z_dev, bits, stats_dev, combined_regions, want_images)
+    return merged_regions, merged_images
+
+
+def get_cell_clusters_from_distances(z_slice, cell_pos, cell_clusters, cell_types):
+    """tiff_analysis.py:791-824.  Returns (merged_regions, merged_images)."""
+    z_dev, was = _to_dev_u8(z_slice)
+    all_regions = [r for regs in list(cell_pos.values()) + list(cell_clusters.values()) for r in regs]
+    stats_dev = _stats_from_regions(all_regions, z_dev.device)
+    merged_regions, merged_images = _clusters_from_distances(z_dev, stats_dev, cell_pos, cell_clusters, cell_types, True)
+    return merged_regions, {k: _back(v, was) for k, v in merged_images.items()}
+
+
+def get_merged_regions(binary_image, og_cell_regions):
+    """tiff_analysis.py:826-883.  Returns (merged_regions, merged_image)."""
+    b_dev, was = _to_dev_u8(binary_image)
+    b_dev = (b_dev != 0).to(torch.uint8)
+    stats_dev = _stats_from_regions(og_cell_regions, b_dev.device)
+    merged_regions, merged_image = _merged_regions_dev(b_dev, 1 << 1, stats_dev, og_cell_regions, True)
+    return merged_regions, _back(merged_image, was)
+
+
+def _fill_particle_dev(ds_dev, particle_label, cell_label, overlap_label):
+    out, area = ops.fill_particle(ds_dev, particle_label, cell_label, overlap_label, DILATION_RADIUS, DISTANCE_THRESHOLD)
+    return out, area
+
+
+def fill_particle_area(ds_arr, particle_label, cell_label, overlap_label):
+    """tiff_analysis.py:982-1015.  Returns (updated_ds_arr, overlap_area); the input is not modified (:1010)."""
+    ds_dev, was = _to_dev_u8(ds_arr)
+    out, area = _fill_particle_dev(ds_dev, particle_label, cell_label, overlap_label)
+    res = _back(out[0], was)
+    if not was:
+        res = res.astype(np.asarray(ds_arr).dtype, copy=False)
+    return res, int(area[0].item())
+
+
+def recreate_particle_area(ds_arr, cell_types, particle_area):
+    """tiff_analysis.py:931-950: one fill per cell class, each on the output of the previous one."""
+    particle_label = None
+    for key, value in cell_types.items():
+        if value == "Particle":
+            particle_label = key
+    ds_dev, was = _to_dev_u8(ds_arr)
+    touched = False
+    for cell_type_label, cell_type in cell_types.items():
+        if cell_type not in CELL_TYPES:
+            continue
+        if particle_label is None:
+            raise TypeError("no 'Particle' entry in cell_types")  # the reference fails inside fill_particle_area
+        ds_dev, area = _fill_particle_dev(ds_dev, particle_label, cell_type_label, particle_label)
+        particle_area += int(area[0].item())
+        touched = True
+    if not touched:
+        return ds_arr, particle_area
+    res = _back(ds_dev[0], was)
+    if not was:
+        res = res.astype(np.asarray(ds_arr).dtype, copy=False)
+    return res, particle_area
+
+
+def get_cell_counts_and_densities(cell_pos, cell_clusters, particle_area):
+    """tiff_analysis.py:1018-1038 (host arithmetic on the region table)."""
+    cell_count, cell_density, cell_area_ratio = {}, {}, {}
+    particle_area = particle_area / (PX_TO_UM_CONV ** 2)
+    for cell_type, cell_array in cell_pos.items():
+        if cell_type not in CELL_TYPES:
+            continue
+        cluster_cells = 0
+        for cluster in cell_clusters[cell_type]:
+            cluster_cells += cluster.cells
+        cell_count[cell_type] = len(cell_array) + cluster_cells
+        cell_area = np.sum([np.int64(cell.area) for cell in cell_array])
+        for cluster in cell_clusters[cell_type]:
+            cell_area += cluster["area"]
+        area = cell_area / (PX_TO_UM_CONV ** 2)
+        cell_density[cell_type] = round(cell_count[cell_type] / particle_area, 5)
+        cell_area_ratio[cell_type] = round(area / particle_area, 5)
+    return cell_count, cell_density, cell_area_ratio
+
+
+def combine_cell_positions_and_clusters(dapi_channel, other_channel):
+    """tiff_analysis.py:252-287: drop DAPI cells that overlap cells of the other channel by > 10 %."""
+    d_dev, was = _to_dev_u8(dapi_channel)
+    o_dev, _ = _to_dev_u8(other_channel)
+    out = ops.remove_overlapping(d_dev, o_dev, DAPI_RFP_OVERLAP_THRESHOLD)
+    res = _back(out[0], was)
+    if not was:
+        res = res.astype(np.asarray(dapi_channel).dtype, copy=False)
+    return res
+
+
+def get_rfp_base_arr(rfp_arr, cell_strains):
+    """tiff_analysis.py:224-231 (in-place class remap)."""
+    if cell_strains == ["6B07"] or cell_strains == ["6B07", "C3M10"]:
+        rfp_arr[rfp_arr == 1] = 4
+        rfp_arr[rfp_arr == 2] = 5
+    else:
+        rfp_arr[rfp_arr == 2] = 4
+        rfp_arr[rfp_arr == 3] = 5
+    return rfp_arr
+
+
+def combine_channels(rfp_base, channel_ds_arrs, cell_strains):
+    """tiff_analysis.py:233-249."""
+    for strain in cell_strains:
+        if strain == "3D05":
+            continue
+        channel_name = STRAIN_MAP[strain]
+        for val, strain_name in BASE_TYPE_MAP.items():
+            if strain_name == strain:
+                rfp_base[channel_ds_arrs[channel_name] == 1] = val
+    return rfp_base
+
+
+def normalize_ds_arr(ds_arr):
+    """tiff_analysis.py:727-737."""
+    if ds_arr.shape[-1] == 1:
+        return np.squeeze(ds_arr)
+    elif ds_arr.shape[0] == 1:
+        return ds_arr[0]
+    elif ds_arr.shape[0] == 2048 and ds_arr.shape[1] == 2048:
+        return ds_arr
+    else:
+        raise ValueError(f"DS arr shape is not (2048,2048,1) or (1,2048,2048) or (2048,2048). Shape: {ds_arr.shape}")
+
+
+def get_strains_from_file(file_name):
+    """tiff_analysis.py:673-678."""
+    return [cell_type for cell_type in CELL_TYPES if cell_type in file_name.upper()]
+
+
+def get_channel_from_file(file_name):
+    """tiff_analysis.py:680-687."""
+    channels = [channel for channel in CHANNELS if channel in file_name.upper()]
+    if len(channels) > 1:
+        raise ValueError("More than one channel found in file path")
+    return channels[0]
+
+
+def get_cell_type_map(file_path):
+    """tiff_analysis.py:694-702."""
+    cell_types = get_strains_from_file(file_path)
+    cell_type_map = {}
+    for i, cell_type in enumerate(cell_types):
+        cell_type_map[i + 1] = cell_type
+    cell_type_map[i + 2] = "Particle"  # UnboundLocalError without any strain in the name, like the reference
+    cell_type_map[i + 3] = "Background"
+    return cell_type_map
+
+
+def get_cell_type_map_from_channel(strain_types, channel):
+    """tiff_analysis.py:709-712."""
+    if (strain_types == ["6B07"] and channel == "RFP") or (strain_types == ["6B07", "C3M10"] and channel == "RFP"):
+        return {1: "Particle", 2: "Background"}
+    return {1: CHANNEL_MAP[channel], 2: "Particle", 3: "Background"}
+
+
+def get_pos_and_density_file_names(cur_folder):
+    """tiff_analysis.py:619-624."""
+    cur_folder_split = cur_folder.split("/")
+    density_info_file_name = f"{cur_folder_split[-3]}_{cur_folder_split[-2]}_cell_density_info.csv"
+    density_info_file_path = os.path.join(cur_folder, "..", density_info_file_name)
+    cell_pos_file_name = os.path.join(cur_folder, f"{cur_folder_split[-1]}_cell_pos.csv")
+    return density_info_file_path, cell_pos_file_name
+
+
+def write_cell_position_info(cell_positions, cell_clusters, csv_output_file, particle_area):
+    """tiff_analysis.py:1047-1063 (csv.writer default dialect, file opened without newline='')."""
+    particle_area = particle_area / (PX_TO_UM_CONV ** 2)
+    with open(csv_output_file, "w") as f:
+        writer = csv.writer(f)
+        writer.writerow(["strain", "cell_type", "x_pos", "y_pos", "cell_area", "cell_area_ratio", "cell_count"])
+        for strain_type, pos in cell_positions.items():
+            for p in pos:
+                cell_pos = p.centroid
+                area = p.area / (PX_TO_UM_CONV ** 2)
+                area_ratio = area / particle_area
+                writer.writerow([strain_type, "cell", round(cell_pos[1], 2), round(cell_pos[0], 2), round(area, 5),
+                                 round(area_ratio, 8), 1])
+        for strain_type, cluster in cell_clusters.items():
+            for c in cluster:
+                pos = c.centroid
+                area = c.area / (PX_TO_UM_CONV ** 2)
+                area_ratio = area / particle_area
+                writer.writerow([strain_type, "cluster", round(pos[1], 2), round(pos[0], 2), area, round(area_ratio, 8), c.cells])
+
+
+def write_merged_cell_position_info(merged_clusters, csv_output_file, particle_area):
+    """tiff_analysis.py:1065-1075."""
+    particle_area = particle_area / (PX_TO_UM_CONV ** 2)
+    with open(csv_output_file, "w") as f:
+        writer = csv.writer(f)
+        writer.writerow(["strain_type", "x_pos", "y_pos", "cell_area", "cell_area_ratio", "cell_num"])
+        for strain_type, pos in merged_clusters.items():
+            for p in pos:
+                cell_pos = p["centroid"]
+                area = p["area"] / (PX_TO_UM_CONV ** 2)
+                area_ratio = area / particle_area
+                writer.writerow([strain_type, round(cell_pos[1], 2), round(cell_pos[0], 2), round(area, 5),
+                                 round(area_ratio, 8), len(p["regions"])])
+
+
+def write_density_info(csv_output_file, h5_folder, cell_density, cell_area_ratio, cell_count):
+    """tiff_analysis.py:1078-1107: rows of the same folder are replaced, others kept."""
+    header = ["folder", "strain", "cell_density", "cell_area_ratio", "cell_count"]
+    existing_data = []
+    path_exists = os.path.exists(csv_output_file)
+    data_exists = False
+    if path_exists:
+        with open(csv_output_file, "r") as f:
+            reader = csv.reader(f)
+            next(reader)
+            for row in reader:
+                if row[0] == h5_folder:
+                    data_exists = True
+                else:
+                    existing_data.append(row)
+    if data_exists:
+        with open(csv_output_file, "w") as f:
+            writer = csv.writer(f)
+            writer.writerow(header)
+            writer.writerows(existing_data)
+    with open(csv_output_file, "a") as f:
+        writer = csv.writer(f)
+        if not path_exists:
+            writer.writerow(header)
+        for strain in cell_density:
+            writer.writerow([h5_folder, strain, cell_density[strain], cell_area_ratio[strain], cell_count[strain]])
+
+
+def read_class_map(path):
+    """The reference reads the first dataset of an ilastik .h5 (tiff_analysis.py:118-121, 639-642).
+    h5py is optional here; ``.npy`` files are always accepted."""
+    if path.endswith(".npy"):
+        return np.load(path, allow_pickle=False)
+    try:
+        import h5py
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("reading .h5 class maps needs h5py; save the class map as .npy instead") from e
+    with h5py.File(path, "r") as f:
+        return f[next(iter(f.keys()))][()]
+
+
+def process_single_h5_file(cur_folder, file_path):
+    """tiff_analysis.py:627-671 without the matplotlib figures: the three CSVs."""
+    full_file_path = os.path.join(cur_folder, file_path)
+    density_info_file_path, cell_pos_file_name = get_pos_and_density_file_names(cur_folder)
+    processed_folder = cur_folder.split("/")[-1]
+    cell_types = get_cell_type_map(file_path)
+    if len(cell_types) == 0:
+        raise ValueError("Cell type not found in file path")
+    ds_arr = normalize_ds_arr(read_class_map(full_file_path))
+    ds_arr_denoised = median_filter(ds_arr, size=DENOISE_SIZE)
+    cell_positions, cell_clusters, particle_area, merged_clusters = get_cell_positions_and_areas(
+        ds_arr_denoised, cell_types, merged=True)
+    cell_count, cell_density, cell_area_ratio = get_cell_counts_and_densities(cell_positions, cell_clusters, particle_area)
+    _, particle_area = recreate_particle_area(ds_arr_denoised, cell_types, particle_area)
+    write_cell_position_info(cell_positions, cell_clusters, cell_pos_file_name, particle_area)
+    merged_file_name = cell_pos_file_name.replace("_cell_pos.csv", "_merged_cell_pos.csv")
+    write_merged_cell_position_info(merged_clusters, merged_file_name, particle_area)
+    write_density_info(density_info_file_path, processed_folder, cell_density, cell_area_ratio, cell_count)

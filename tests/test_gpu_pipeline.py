@@ -1,0 +1,129 @@
+"""The batched device pipeline (full chain) against the CPU oracle, frame by frame."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_frames(stacks, ct):
+    out = []
+    for st in stacks:
+        try:
+            out.append(orc.segment_frame(st, ct))
+        except ValueError:
+            out.append(None)
+    return out
+
+
+def _good_seeds(n, H, W, ct, start, ties=False):
+    from particle_col_image_segmentation_amd import synth
+    seeds, s = [], start
+    while len(seeds) < n:
+        try:
+            orc.segment_frame(synth.gen_frame(s, H, W, ties=ties), ct, merged=False)
+            seeds.append(s)
+        except ValueError:
+            pass
+        s += 1
+    return seeds
+
+
+@pytest.mark.parametrize("H,W,ties", [(160, 192, False), (128, 128, True), (256, 256, False)])
+def test_pipeline_matches_oracle(H, W, ties):
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the HIP path has no CPU fallback")
+    from particle_col_image_segmentation_amd import synth
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline, RATIOS_5
+    ct = dict(synth.CELL_TYPES_5)
+    seeds = _good_seeds(3, H, W, ct, 300, ties)
+    stacks = np.stack([synth.gen_frame(s, H, W, ties=ties) for s in seeds])
+    pipe = FramePipeline(ct)
+    res = pipe.run(torch.from_numpy(stacks).cuda())
+    res.check()
+    tabs = pipe.tables(res, frame_ids=seeds)
+    refs = _oracle_frames(stacks, ct)
+    host = lambda k: res[k].cpu().numpy()
+    den, labels, counts, stats, cc_sums = host("denoised"), host("labels"), host("counts"), host("stats"), host("cc_sums")
+    rec, ws, kind, cells, slot_of = host("recreated"), host("ws_labels"), host("kind"), host("cells"), host("slot_of")
+    pa, ovl, nmk = host("particle_area"), host("overlap_area"), host("n_markers")
+    ws_stats, ws_sums = host("ws_stats"), host("ws_sums")
+    names = pipe.tables_.slot_names
+    for b, ref in enumerate(refs):
+        assert ref is not None
+        np.testing.assert_array_equal(den[b], ref["denoised"])
+        np.testing.assert_array_equal(labels[b], ref["label_im"])
+        n = int(ref["label_im"].max())
+        assert int(counts[b]) == n
+        np.testing.assert_array_equal(stats[b, :n], orc.region_table(ref["label_im"]))
+        np.testing.assert_allclose(cc_sums[b, :n], ref["cc_sums"], rtol=1e-9, atol=0)  # float sums: 1e-6 budget
+        assert int(pa[b]) == ref["particle_area"]
+        np.testing.assert_array_equal(rec[b], ref["recreated"])
+        assert int(pa[b] + ovl[b]) == ref["particle_area2"]
+        np.testing.assert_array_equal(ws[b], ref["refine"]["labels"])
+        m = int(ref["refine"]["markers"].max())
+        assert int(nmk[b]) == m
+        np.testing.assert_array_equal(ws_stats[b, :m], orc.region_table(ref["refine"]["labels"], m))
+        np.testing.assert_allclose(ws_sums[b, :m], ref["roi_sums"], rtol=1e-9, atol=0)
+        # classification and cluster cell counts
+        for s, name in enumerate(names):
+            exp_cells = [r.label for r in ref["cell_pos"].get(name, [])]
+            exp_clu = [r.label for r in ref["cell_clusters"].get(name, [])]
+            got_cells = list(np.nonzero((kind[b, :n] == 1) & (slot_of[b, :n] == s))[0] + 1)
+            got_clu = list(np.nonzero((kind[b, :n] == 2) & (slot_of[b, :n] == s))[0] + 1)
+            assert got_cells == exp_cells and got_clu == exp_clu
+            assert [int(cells[b, l - 1]) for l in exp_clu] == [r.cells for r in ref["cell_clusters"].get(name, [])]
+        # merged groups, per type and combined
+        for s, g in res["groups"].items():
+            key = "combined" if s == 4 else names[s]
+            exp = ref["merged_clusters"].get(key, [])
+            ng = int(g["n_groups"][b])
+            assert ng == len(exp)
+            gst = g["group_stats"][b, :ng].cpu().numpy()
+            k = int(res["n_list"][b, s])
+            lst = res["region_list"][b, s, :k].cpu().numpy()
+            gof = g["group_of"][b, :k].cpu().numpy()
+            for gi, e in enumerate(exp):
+                assert int(gst[gi, 0]) == e["area"]
+                assert tuple(int(v) for v in gst[gi, 3:7]) == tuple(e["bbox"])
+                assert list(lst[gof == gi + 1] + 1) == [r.label for r in e["regions"]]
+                np.testing.assert_allclose([gst[gi, 1] / gst[gi, 0], gst[gi, 2] / gst[gi, 0]], e["centroid"], rtol=1e-12)
+        # per-frame counts / densities (A9)
+        cnt, dens, ratio = ref["counts"]
+        fr = tabs["frames"][b]
+        cols = tabs["frames_columns"]
+        for name in cnt:
+            assert fr[cols.index(name + "_count")] == cnt[name]
+            assert fr[cols.index(name + "_density")] == dens[name]
+            assert fr[cols.index(name + "_area_ratio")] == ratio[name]
+    # ROI table: ratios within 1e-6 relative of the oracle's
+    rois = tabs["rois"]
+    for b, ref in enumerate(refs):
+        rows = rois[rois[:, 0] == seeds[b]]
+        exp, _ = orc.roi_activity_table(ref["refine"]["labels"], stacks[b], ratios=RATIOS_5)
+        assert rows.shape[0] == exp.shape[0]
+        np.testing.assert_allclose(rows[:, 5:5 + 5], exp[:, 2:7], rtol=1e-9)
+        np.testing.assert_allclose(rows[:, 10:12], exp[:, 7:9], rtol=1e-6)
+
+
+def test_pipeline_reports_reference_crash():
+    """A type with clusters but no single cell makes the reference raise int(NaN) (tiff_analysis.py:776-781)."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from particle_col_image_segmentation_amd import synth
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline
+    H = W = 64
+    yy, xx = np.mgrid[0:H, 0:W]
+    st = np.full((1, 5, H, W), 0.05, np.float32)
+    st[0, 4] = 0.5
+    st[0, 0][(yy - 20) ** 2 + (xx - 20) ** 2 <= 100] = 0.9      # one class-1 component of area >= 200, no single cells
+    st[0, 2][40:60, 30:60] = 0.9
+    ct = dict(synth.CELL_TYPES_5)
+    with pytest.raises(ValueError, match="cannot convert float NaN to integer"):
+        orc.segment_frame(st[0], ct)
+    res = FramePipeline(ct).run(torch.from_numpy(st).cuda())
+    assert int(res["nan_flag"][0]) == 1
+    with pytest.raises(ValueError, match="cannot convert float NaN to integer"):
+        res.check()

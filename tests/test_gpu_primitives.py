@@ -267,17 +267,26 @@ def test_merge_groups(ops):
     stats, cls_out, _, _ = ops.region_reduce(dev(labs), counts, dev(cm))
     dil = ops.dilate_disk(dev(cm), (1 << 1) | (1 << 2), 2)
     dl, _ = ops.label_bool8(dil)
-    area = stats[:, :, 0]
-    select = ((cls_out == 1) | (cls_out == 2)) & (area >= 20)
-    group_of, n_groups = ops.merge_groups(dl, stats, select.to(torch.uint8), counts)
+    lists, regs_all = [], []
     for i in range(2):
         regs = [r for r in orc.regionprops(labs[i]) if cm[i][r.first] in (1, 2) and r.area >= 20]
-        groups, _ = orc.get_merged_regions((cm[i] == 1) | (cm[i] == 2), regs)
-        exp = np.zeros(int(counts[i]), np.int32)
+        regs = [r for r in regs if r.area < 200] + [r for r in regs if r.area >= 200]  # cells then clusters (:796)
+        regs_all.append(regs)
+        lists.append([r.label - 1 for r in regs])
+    cap = max(len(l) for l in lists) + 3
+    rl = np.full((2, cap), -1, np.int32)
+    for i, l in enumerate(lists):
+        rl[i, :len(l)] = l
+    n_list = torch.tensor([len(l) for l in lists], dtype=torch.int32).cuda()
+    group_of, n_groups = ops.merge_groups(dl, stats, dev(rl), n_list)
+    for i in range(2):
+        groups, _ = orc.get_merged_regions((cm[i] == 1) | (cm[i] == 2), regs_all[i])
+        exp = np.zeros(len(lists[i]), np.int32)
+        pos = {r.label: k for k, r in enumerate(regs_all[i])}
         for gi, g in enumerate(groups):
             for r in g["regions"]:
-                exp[r.label - 1] = gi + 1
-        np.testing.assert_array_equal(host(group_of)[i, :int(counts[i])], exp)
+                exp[pos[r.label]] = gi + 1
+        np.testing.assert_array_equal(host(group_of)[i, :len(lists[i])], exp)
         assert int(n_groups[i]) == len(groups)
 
 
