@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpixels/s segmented on synthetic 5-channel 1024x1024 frames (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W            # N = 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the full per-frame chain (FramePipeline.run: class map -> median -> label -> region table
++ isotope sums -> classification -> proximity merge -> particle fill -> refine (EDT, maxima, watershed) -> ROI sums)
+over one batch of 64 frames of 1024x1024x5 float32 that is already resident in HBM (BASELINE config 2).  Frames are
+independent, so N ranks each process their own batch (weak scaling, no data-path collective); the only exchange is
+the RCCL all-gather of the ROI table, done once after the timed region.
+
+The JSON line carries `roofline` (dominant kernel, HIP events recorded on the launch stream inside the timed
+region) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample; reported, not the
+target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+CHAIN_BYTES_PER_PIXEL = 28  # 5 x f32 in + int32 class-CC mask + int32 ROI mask
+
+# algorithmic (compulsory) bytes per pixel of one launch of each kernel, stated in DESIGN.md
+KERNEL_BYTES_PER_PIXEL = {
+    "argmax_kernel": 21.0, "median5_kernel": 2.0, "ccl_tile_kernel": 5.0, "ccl_border_kernel": 0.0,
+    "ccl_flatten_count_kernel": 8.0, "ccl_assign_kernel": 4.0, "ccl_relabel_kernel": 8.0, "ccl_flatten_kernel": 8.0,
+    "region_reduce_kernel": 24.0, "edt_bits_kernel": 1.0, "edt_row_kernel": 4.0, "ws_init_kernel": 21.0,
+    "ws_relax_kernel": 12.0, "ws_propagate_kernel": 12.0, "ws_check_kernel": 8.0, "ws_exact_kernel": 21.0,
+    "locmax_candidates_kernel": 8.0, "locmax_bad_kernel": 8.0,
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = 2 per core)")
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event table to stderr")
+    return ap.parse_args()
+
+
+def _cpu_frame(args):
+    seed, size = args
+    from oracle import oracle as orc
+    from particle_col_image_segmentation_amd import synth
+    st = synth.gen_frame(seed, size, size)
+    t0 = time.perf_counter()
+    try:
+        orc.segment_frame(st, dict(synth.CELL_TYPES_5))
+    except ValueError:
+        pass  # the reference's int(NaN) frames still cost their time
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(size, n_frames):
+    """CPU oracle (bit-exact restatement of the reference chain, 'port') on this box's host cores, one frame per
+    process; bounded sample so that the default run stays within minutes."""
+    import multiprocessing as mp
+    from oracle import oracle as orc
+    orc.build()
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    n = n_frames or 2 * cores
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        per = pool.map(_cpu_frame, [(900 + i, size) for i in range(n)])
+    wall = time.perf_counter() - t0
+    return {"value": round(n * size * size / wall / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "%d synthetic %dx%dx5 frames, full chain incl. O(R) merge, %d processes, wall %.1f s "
+                      "(%.2f s/frame/core)" % (n, size, size, cores, wall, sum(per) / len(per))}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from particle_col_image_segmentation_amd import _lib, synth
+    from particle_col_image_segmentation_amd.distributed import all_gather_table
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline
+
+    B, H, W = args.batch, args.size, args.size
+    lib = _lib.load()
+    stack = synth.gen_batch_torch(10_000 + rank * B, B, H, W, dev)
+    pipe = FramePipeline(dict(synth.CELL_TYPES_5))
+    res = None
+    for _ in range(args.warmup):
+        res = pipe.run(stack)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    lib.pcseg_timing_enable(1)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = pipe.run(stack)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    nbytes = lib.pcseg_timing_report(None, 0)
+    import ctypes
+    buf = ctypes.create_string_buffer(nbytes + 16)
+    lib.pcseg_timing_report(buf, nbytes + 16)
+    lib.pcseg_timing_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res.check()
+    tie_frames = int(res["tie_flags"].sum().item())
+
+    # the one exchange step of the path: all-gather of the per-ROI table (outside the timed region)
+    tables = pipe.tables(res, frame_ids=[rank * B + i for i in range(B)])
+    rois = torch.from_numpy(tables["rois"]).to(dev)
+    gathered = all_gather_table(rois)
+    n_rois = int(gathered.shape[0])
+
+    if rank == 0:
+        kernels = {}
+        for line in buf.value.decode().splitlines():
+            name, calls, ms = line.split("\t")
+            kernels[name] = (int(calls), float(ms))
+        if args.kernel_table:
+            for name, (calls, ms) in sorted(kernels.items(), key=lambda kv: -kv[1][1]):
+                print("%10.3f ms %7d launches %9.2f us/launch  %s" % (ms, calls, 1e3 * ms / calls, name), file=sys.stderr)
+        dom = max(kernels.items(), key=lambda kv: kv[1][1])
+        dom_name, (dom_calls, dom_ms) = dom
+        short = dom_name.split("<")[0].split(" ")[0].strip("()")
+        bpp = KERNEL_BYTES_PER_PIXEL.get(short, float("nan"))
+        avg_s = dom_ms / dom_calls / 1e3
+        achieved = bpp * B * H * W / avg_s / 1e9
+        total_kernel_ms = sum(ms for _, ms in kernels.values())
+        value = world * B * H * W * args.steps / elapsed / 1e6
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(short)
+        out = {
+            "metric": "Mpixels/sec segmented (5-ch 1024x1024 TIFF), ROI mask IoU=1.0",
+            "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 planes / u8 class maps / int32 labels / f64 ROI sums", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: batch of %d frames %dx%dx5 float32 per GPU, full kernel chain, "
+                                   "inputs resident in HBM" % (B, H, W),
+                       "frames_per_gpu": B, "height": H, "width": W, "planes": 5, "parallelism": "frames x%d" % world,
+                       "tie_fallback_frames_last_step": tie_frames, "gathered_roi_rows": n_rois},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "launches_per_step": dom_calls / args.steps,
+                         "avg_launch_us": round(1e6 * avg_s, 2), "algorithmic_bytes_per_pixel": bpp,
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "share_of_kernel_time": round(dom_ms / total_kernel_ms, 4),
+                         "chain_bytes_per_pixel": CHAIN_BYTES_PER_PIXEL,
+                         "chain_achieved_GBps": round(CHAIN_BYTES_PER_PIXEL * value / world / 1e3, 3),
+                         "chain_frac": round(CHAIN_BYTES_PER_PIXEL * value / world / 1e3 / HBM_PEAK_GBS, 6)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H, args.cpu_frames)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,13 @@ int pcseg_version(void);
 const char *pcseg_last_error(void);
 int pcseg_device_count(void);
 
+/* ---- measurement aid (bench.py's roofline leg): when enabled, every kernel launch is bracketed by hipEvents
+ * recorded on the launch stream.  pcseg_timing_report waits for them and writes one line per kernel
+ * "name<TAB>launches<TAB>total_ms"; it returns the number of bytes written (needed size when buf is NULL)
+ * and clears the records.  Off by default. */
+void pcseg_timing_enable(int on);
+int pcseg_timing_report(char *buf, size_t buf_bytes);
+
 /* ---- ingest: class map = argmax over the C planes + 1 (what ilastik's
  * "Simple Segmentation" export holds; read at tiff_analysis.py:118-121, 639-642) */
 int pcseg_argmax_planes_f32(const float *stack, uint8_t *cls, int B, int C, int H, int W, pcseg_stream_t stream);

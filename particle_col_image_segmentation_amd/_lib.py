@@ -23,6 +23,8 @@ SIGNATURES = {
     "pcseg_version": (c_int, []),
     "pcseg_last_error": (c_char_p, []),
     "pcseg_device_count": (c_int, []),
+    "pcseg_timing_enable": (None, [c_int]),
+    "pcseg_timing_report": (c_int, [c_char_p, c_size_t]),
     "pcseg_argmax_planes_f32": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "pcseg_median5_u8": (c_int, [_P, _P, _I, _I, _I, _P]),
     "pcseg_ccl_workspace_bytes": (c_size_t, [_I, _I, _I]),

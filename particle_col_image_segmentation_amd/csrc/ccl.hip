@@ -285,11 +285,11 @@ template <typename KeyFn, bool CONN8>
 static int ccl_roots(KeyFn keyfn, int *parent, int B, int H, int W, hipStream_t s)
 {
     dim3 tgrid((W + CCL_TW - 1) / CCL_TW, (H + CCL_TH - 1) / CCL_TH, B);
-    hipLaunchKernelGGL((ccl_tile_kernel<KeyFn, CONN8>), tgrid, dim3(256), 0, s, keyfn, parent, H, W);
+    PCSEG_LAUNCH((ccl_tile_kernel<KeyFn, CONN8>), tgrid, dim3(256), 0, s, keyfn, parent, H, W);
     PCSEG_CHECK_LAUNCH();
     if (tgrid.x > 1 || tgrid.y > 1) {
         dim3 bgrid((W + 63) / 64, (H + 3) / 4, B);
-        hipLaunchKernelGGL((ccl_border_kernel<KeyFn, CONN8>), bgrid, dim3(256), 0, s, keyfn, parent, H, W);
+        PCSEG_LAUNCH((ccl_border_kernel<KeyFn, CONN8>), bgrid, dim3(256), 0, s, keyfn, parent, H, W);
         PCSEG_CHECK_LAUNCH();
     }
     return PCSEG_OK;
@@ -302,13 +302,13 @@ static int ccl_compact(int *parent, int *blockcount, int nblk, int *labels, int 
 {
     int64_t n = (int64_t)H * W;
     dim3 grid(nblk, B);
-    hipLaunchKernelGGL((ccl_flatten_count_kernel<Pred>), grid, dim3(256), 0, s, parent, blockcount, pred, n, nblk, flatten);
+    PCSEG_LAUNCH((ccl_flatten_count_kernel<Pred>), grid, dim3(256), 0, s, parent, blockcount, pred, n, nblk, flatten);
     PCSEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, blockcount, counts, nblk);
+    PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, blockcount, counts, nblk);
     PCSEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL((ccl_assign_kernel<Pred>), grid, dim3(256), 0, s, parent, blockcount, labels, pred, n, nblk);
+    PCSEG_LAUNCH((ccl_assign_kernel<Pred>), grid, dim3(256), 0, s, parent, blockcount, labels, pred, n, nblk);
     PCSEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL((ccl_relabel_kernel<Pred>), grid, dim3(256), 0, s, parent, labels, pred, n);
+    PCSEG_LAUNCH((ccl_relabel_kernel<Pred>), grid, dim3(256), 0, s, parent, labels, pred, n);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }
@@ -514,7 +514,7 @@ int pcseg_compact_labels(const int32_t *roots, int32_t *labels, int32_t *counts,
         return PCSEG_ERR_WORKSPACE;
     }
     int64_t total = (int64_t)B * H * W;
-    hipLaunchKernelGGL(roots_to_parent_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, roots, ws.parent, total);
+    PCSEG_LAUNCH(roots_to_parent_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, roots, ws.parent, total);
     PCSEG_CHECK_LAUNCH();
     return ccl_compact(ws.parent, ws.blockcount, ws.nblk, labels, counts, PredAll(), true, B, H, W, s);
 }
@@ -541,12 +541,12 @@ int pcseg_fill_holes(const uint8_t *mask, uint8_t *out, int B, int H, int W, voi
     int rc = ccl_roots<KeyZeroU8, false>(KeyZeroU8{mask}, ws.parent, B, H, W, s);
     if (rc) return rc;
     dim3 g1((unsigned)((n + 255) / 256), B);
-    hipLaunchKernelGGL(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);
+    PCSEG_LAUNCH(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);
     PCSEG_CHECK_LAUNCH();
     PCSEG_CHECK_HIP(hipMemsetAsync(flag, 0, (size_t)B * n, s));
-    hipLaunchKernelGGL(border_flag_kernel, dim3((2 * W + 2 * H + 255) / 256, B), dim3(256), 0, s, ws.parent, flag, H, W);
+    PCSEG_LAUNCH(border_flag_kernel, dim3((2 * W + 2 * H + 255) / 256, B), dim3(256), 0, s, ws.parent, flag, H, W);
     PCSEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(fill_holes_out_kernel, g1, dim3(256), 0, s, mask, ws.parent, flag, out, n);
+    PCSEG_LAUNCH(fill_holes_out_kernel, g1, dim3(256), 0, s, mask, ws.parent, flag, out, n);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }
@@ -577,19 +577,19 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
     PCSEG_CHECK_HIP(hipMemsetAsync(nonconst, 0, sizeof(int) * B, s));
     PCSEG_CHECK_HIP(hipMemsetAsync(bad, 0, (size_t)B * n, s));
     dim3 g2((W + 63) / 64, (H + 3) / 4, B);
-    hipLaunchKernelGGL(locmax_candidates_kernel, g2, dim3(256), 0, s, img, key, nonconst, H, W);
+    PCSEG_LAUNCH(locmax_candidates_kernel, g2, dim3(256), 0, s, img, key, nonconst, H, W);
     PCSEG_CHECK_LAUNCH();
     int rc = ccl_roots<KeyI32, true>(KeyI32{key}, ws.parent, B, H, W, s);
     if (rc) return rc;
     dim3 g1((unsigned)((n + 255) / 256), B);
-    hipLaunchKernelGGL(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);
+    PCSEG_LAUNCH(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);
     PCSEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(locmax_bad_kernel, g2, dim3(256), 0, s, img, key, ws.parent, bad, H, W);
+    PCSEG_LAUNCH(locmax_bad_kernel, g2, dim3(256), 0, s, img, key, ws.parent, bad, H, W);
     PCSEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(locmax_const_kernel, g1, dim3(256), 0, s, bad, nonconst, n);
+    PCSEG_LAUNCH(locmax_const_kernel, g1, dim3(256), 0, s, bad, nonconst, n);
     PCSEG_CHECK_LAUNCH();
     if (is_max) {
-        hipLaunchKernelGGL(locmax_out_kernel, g1, dim3(256), 0, s, ws.parent, bad, nonconst, is_max, n);
+        PCSEG_LAUNCH(locmax_out_kernel, g1, dim3(256), 0, s, ws.parent, bad, nonconst, is_max, n);
         PCSEG_CHECK_LAUNCH();
     }
     if (markers) {
@@ -623,13 +623,13 @@ int pcseg_remove_overlapping(const uint8_t *dapi, const uint8_t *other, double t
     int rc = ccl_roots<KeyIsOneU8, true>(KeyIsOneU8{dapi}, ws.parent, B, H, W, s);
     if (rc) return rc;
     dim3 g1((unsigned)((n + 255) / 256), B);
-    hipLaunchKernelGGL(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);
+    PCSEG_LAUNCH(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);
     PCSEG_CHECK_LAUNCH();
     PCSEG_CHECK_HIP(hipMemsetAsync(area, 0, sizeof(int) * (size_t)B * n, s));
     PCSEG_CHECK_HIP(hipMemsetAsync(ov, 0, sizeof(int) * (size_t)B * n, s));
-    hipLaunchKernelGGL(overlap_count_kernel, g1, dim3(256), 0, s, ws.parent, other, area, ov, n);
+    PCSEG_LAUNCH(overlap_count_kernel, g1, dim3(256), 0, s, ws.parent, other, area, ov, n);
     PCSEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(overlap_out_kernel, g1, dim3(256), 0, s, dapi, ws.parent, area, ov, threshold, out, n);
+    PCSEG_LAUNCH(overlap_out_kernel, g1, dim3(256), 0, s, dapi, ws.parent, area, ov, threshold, out, n);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

@@ -39,6 +39,20 @@ void set_error(const char *fmt, ...);
         }                                                                                  \
     } while (0)
 
+// optional per-kernel timing (pcseg_timing_enable): hipEvents recorded around every launch ON THE LAUNCH STREAM
+struct LaunchTimer {
+    hipStream_t stream;
+    int slot;
+    LaunchTimer(const char *kernel, const char *where, hipStream_t s);  // where = __PRETTY_FUNCTION__ (template arguments)
+    ~LaunchTimer();
+};
+
+#define PCSEG_LAUNCH(kernel, grid, block, lds, stream, ...)                 \
+    do {                                                                    \
+        pcseg::LaunchTimer _timer(#kernel, __PRETTY_FUNCTION__, stream);                         \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);  \
+    } while (0)
+
 inline int check_shape(int B, int H, int W)
 {
     // linear indices are int32 per frame; rows/cols are stored as uint16 in the EDT scratch

@@ -246,14 +246,14 @@ static int edt_run(Fg fg, Epi epi, unsigned long long *count, int B, int H, int 
     }
     PCSEG_CHECK_HIP(hipMemsetAsync(ws.any_bg, 0, sizeof(int) * B, s));
     dim3 g1((W + 255) / 256, ws.nch, B);
-    hipLaunchKernelGGL((edt_bits_kernel<Fg>), g1, dim3(256), 0, s, fg, ws.bits, ws.any_bg, H, W, ws.nch);
+    PCSEG_LAUNCH((edt_bits_kernel<Fg>), g1, dim3(256), 0, s, fg, ws.bits, ws.any_bg, H, W, ws.nch);
     PCSEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(edt_carry_kernel, dim3((W + 255) / 256, B), dim3(256), 0, s, ws.bits, ws.up, ws.dn, H, W, ws.nch);
+    PCSEG_LAUNCH(edt_carry_kernel, dim3((W + 255) / 256, B), dim3(256), 0, s, ws.bits, ws.up, ws.dn, H, W, ws.nch);
     PCSEG_CHECK_LAUNCH();
     if (lds > 64 * 1024)
         PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)edt_row_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 g2((H + EDT_RB - 1) / EDT_RB, B);
-    hipLaunchKernelGGL((edt_row_kernel<Epi>), g2, dim3(256), lds, s, ws.bits, ws.up, ws.dn, ws.any_bg, epi, count, H, W, ws.nch);
+    PCSEG_LAUNCH((edt_row_kernel<Epi>), g2, dim3(256), lds, s, ws.bits, ws.up, ws.dn, ws.any_bg, epi, count, H, W, ws.nch);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

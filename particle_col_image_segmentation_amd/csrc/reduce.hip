@@ -434,18 +434,18 @@ int pcseg_region_reduce_n(const int32_t *labels, const int32_t *counts, const ui
     hipStream_t s = (hipStream_t)stream;
     if (overflow) PCSEG_CHECK_HIP(hipMemsetAsync(overflow, 0, sizeof(int32_t) * B, s));
     dim3 gi((cap + 255) / 256, B);
-    hipLaunchKernelGGL(region_init_kernel, gi, dim3(256), 0, s, (long long *)stats, sums, counts, cap, C, H, W);
+    PCSEG_LAUNCH(region_init_kernel, gi, dim3(256), 0, s, (long long *)stats, sums, counts, cap, C, H, W);
     PCSEG_CHECK_LAUNCH();
     dim3 grid((H + RED_ROWS - 1) / RED_ROWS, B);
     if (planes)
-        hipLaunchKernelGGL(region_reduce_kernel<true>, grid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats,
+        PCSEG_LAUNCH(region_reduce_kernel<true>, grid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats,
                            sums, overflow);
     else
-        hipLaunchKernelGGL(region_reduce_kernel<false>, grid, dim3(256), 0, s, labels, planes, C, H, W, cap,
+        PCSEG_LAUNCH(region_reduce_kernel<false>, grid, dim3(256), 0, s, labels, planes, C, H, W, cap,
                            (long long *)stats, sums, overflow);
     PCSEG_CHECK_LAUNCH();
     if (cls) {
-        hipLaunchKernelGGL(region_class_kernel, gi, dim3(256), 0, s, (const long long *)stats, cls, counts, cls_out, cap,
+        PCSEG_LAUNCH(region_class_kernel, gi, dim3(256), 0, s, (const long long *)stats, cls, counts, cls_out, cap,
                            (int64_t)H * W);
         PCSEG_CHECK_LAUNCH();
     }
@@ -479,7 +479,7 @@ int pcseg_merge_groups(const int32_t *dilated_labels, const int64_t *stats, cons
         set_error("merge_groups: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(merge_groups_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dilated_labels,
+    PCSEG_LAUNCH(merge_groups_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dilated_labels,
                        (const long long *)stats, region_list, n_list, group_of, n_groups, key, first, gid, H, W, cap, list_cap);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
@@ -502,7 +502,7 @@ int pcseg_classify_regions(const int64_t *stats, const uint8_t *cls_out, const i
         tab.min_cluster[t] = t < n_slots ? min_cluster[t] : 0x7FFFFFFF;
     }
     tab.n_slots = n_slots;
-    hipLaunchKernelGGL(classify_regions_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)stats, cls_out,
+    PCSEG_LAUNCH(classify_regions_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)stats, cls_out,
                        counts, tab, kind, slot_of, cells, (long long *)particle_area, (long long *)type_stats, region_list, n_list,
                        nan_flag, cap);
     PCSEG_CHECK_LAUNCH();
@@ -515,7 +515,7 @@ int pcseg_group_reduce(const int64_t *stats, const int32_t *region_list, const i
 {
     PCSEG_REQUIRE(stats && region_list && n_list && group_of && n_groups && group_stats && B >= 1 && cap >= 1 && list_cap >= 1,
                   "bad arguments");
-    hipLaunchKernelGGL(group_reduce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)stats, region_list,
+    PCSEG_LAUNCH(group_reduce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)stats, region_list,
                        n_list, group_of, n_groups, (long long *)group_stats, cap, list_cap, H, W);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;

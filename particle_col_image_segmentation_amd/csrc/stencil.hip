@@ -4,6 +4,11 @@
 // median, no MFMA (nothing here is a contraction).
 #include <stdarg.h>
 
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "common.h"
 
 namespace pcseg {
@@ -16,6 +21,37 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+}
+
+// ---------------------------------------------------------------- launch timing
+struct TimingSlot {
+    const char *name, *where;
+    hipEvent_t a, b;
+};
+static std::mutex g_tmutex;
+static bool g_timing = false;
+static std::vector<TimingSlot> g_slots;
+static size_t g_used = 0;
+
+LaunchTimer::LaunchTimer(const char *n, const char *where, hipStream_t s) : stream(s), slot(-1)
+{
+    if (!g_timing) return;
+    std::lock_guard<std::mutex> lk(g_tmutex);
+    if (g_used == g_slots.size()) {
+        TimingSlot t{n, where, nullptr, nullptr};
+        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
+        g_slots.push_back(t);
+    }
+    slot = (int)g_used++;
+    g_slots[slot].name = n;
+    g_slots[slot].where = where;
+    (void)hipEventRecord(g_slots[slot].a, s);
+}
+
+LaunchTimer::~LaunchTimer()
+{
+    if (slot < 0) return;
+    (void)hipEventRecord(g_slots[slot].b, stream);
 }
 
 // ---------------------------------------------------------------- argmax
@@ -233,6 +269,43 @@ extern "C" {
 
 int pcseg_version(void) { return 100; }
 
+void pcseg_timing_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_tmutex);
+    g_timing = on != 0;
+    g_used = 0;
+}
+
+int pcseg_timing_report(char *buf, size_t buf_bytes)
+{
+    std::lock_guard<std::mutex> lk(g_tmutex);
+    std::map<std::string, std::pair<long, double>> agg;
+    for (size_t i = 0; i < g_used; ++i) {
+        if (hipEventSynchronize(g_slots[i].b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_slots[i].a, g_slots[i].b) != hipSuccess) continue;
+        // kernel name + the template arguments of the launching function ("[Fg = ..., Epi = ...]")
+        std::string key = g_slots[i].name;
+        const char *br = strchr(g_slots[i].where, '[');
+        if (br) key += std::string(" ") + br;
+        auto &e = agg[key];
+        e.first += 1;
+        e.second += ms;
+    }
+    std::string out;
+    char line[1024];
+    for (auto &kv : agg) {
+        snprintf(line, sizeof line, "%s\t%ld\t%.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        out += line;
+    }
+    if (!buf || buf_bytes == 0) return (int)out.size() + 1;
+    g_used = 0;  // records are consumed only when they are actually written out
+    size_t nbytes = out.size() < buf_bytes - 1 ? out.size() : buf_bytes - 1;
+    memcpy(buf, out.data(), nbytes);
+    buf[nbytes] = 0;
+    return (int)nbytes;
+}
+
 const char *pcseg_last_error(void) { return g_err; }
 
 int pcseg_device_count(void)
@@ -249,10 +322,10 @@ int pcseg_argmax_planes_f32(const float *stack, uint8_t *cls, int B, int C, int 
     hipStream_t s = (hipStream_t)stream;
     if ((n & 3) == 0) {
         dim3 grid((unsigned)((n / 4 + 255) / 256), B);
-        hipLaunchKernelGGL(argmax_kernel<true>, grid, dim3(256), 0, s, stack, cls, C, n);
+        PCSEG_LAUNCH(argmax_kernel<true>, grid, dim3(256), 0, s, stack, cls, C, n);
     } else {
         dim3 grid((unsigned)((n + 255) / 256), B);
-        hipLaunchKernelGGL(argmax_kernel<false>, grid, dim3(256), 0, s, stack, cls, C, n);
+        PCSEG_LAUNCH(argmax_kernel<false>, grid, dim3(256), 0, s, stack, cls, C, n);
     }
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
@@ -262,7 +335,7 @@ int pcseg_median5_u8(const uint8_t *in, uint8_t *out, int B, int H, int W, pcseg
 {
     PCSEG_REQUIRE(in && out && in != out && check_shape(B, H, W), "bad arguments");
     dim3 grid((W + MED_TW - 1) / MED_TW, (H + MED_TH - 1) / MED_TH, B);
-    hipLaunchKernelGGL(median5_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, H, W);
+    PCSEG_LAUNCH(median5_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, H, W);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }
@@ -272,7 +345,7 @@ int pcseg_threshold_lt_f32(const float *img, float threshold, uint8_t *mask, int
     PCSEG_REQUIRE(img && mask && check_shape(B, H, W), "bad arguments");
     int64_t total = (int64_t)B * H * W;
     unsigned blocks = (unsigned)((total + 1023) / 1024);
-    hipLaunchKernelGGL(threshold_lt_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, threshold, mask, total);
+    PCSEG_LAUNCH(threshold_lt_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, threshold, mask, total);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }
@@ -281,7 +354,7 @@ int pcseg_morph3x3(const uint8_t *mask, uint8_t *out, int erode, int B, int H, i
 {
     PCSEG_REQUIRE(mask && out && mask != out && check_shape(B, H, W), "bad arguments");
     dim3 grid((W + 63) / 64, (H + 3) / 4, B);
-    hipLaunchKernelGGL(morph3x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, mask, out, erode, H, W);
+    PCSEG_LAUNCH(morph3x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, mask, out, erode, H, W);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }
@@ -299,12 +372,12 @@ int pcseg_otsu_hist_f32(const float *img, int64_t *hist, float *lohi, int B, int
     for (int b = 0; b < B; ++b) PCSEG_CHECK_HIP(hipMemsetAsync(keys + 2 * b, 0xFF, sizeof(unsigned), s));
     unsigned gx = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(minmax_kernel, dim3(gx, B), dim3(256), 0, s, img, keys, n);
+    PCSEG_LAUNCH(minmax_kernel, dim3(gx, B), dim3(256), 0, s, img, keys, n);
     PCSEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(otsu_hist_kernel, dim3(gx, B), dim3(256), 0, s, img, keys, (unsigned long long *)hist, n);
+    PCSEG_LAUNCH(otsu_hist_kernel, dim3(gx, B), dim3(256), 0, s, img, keys, (unsigned long long *)hist, n);
     PCSEG_CHECK_LAUNCH();
     // keys -> float32 lo/hi in place, after every histogram block has read them (stream order)
-    hipLaunchKernelGGL(keys_to_float_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, s, keys, 2 * B);
+    PCSEG_LAUNCH(keys_to_float_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, s, keys, 2 * B);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

@@ -115,18 +115,23 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restric
     }
 }
 
-// (2) label propagation along "neighbour with L == Lmin"
-__global__ void __launch_bounds__(256) ws_propagate_kernel(const unsigned *__restrict__ L, int *__restrict__ F,
+// (2) label propagation along "labelled neighbour whose key equals the minimum key of the neighbours".
+// KeyT = unsigned: key = L;  KeyT = unsigned long long: key = (L << 32) | K2 (second-level order, see below)
+template <typename KeyT>
+__global__ void __launch_bounds__(256) ws_propagate_kernel(const KeyT *__restrict__ K, int *__restrict__ F,
+                                                            const int *__restrict__ frame_flags,
                                                             const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
                                                             int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
 {
-    __shared__ unsigned sL[WS_S * WS_S];
+    __shared__ KeyT sK[WS_S * WS_S];
     __shared__ int sF[WS_S * WS_S];
+    const KeyT KINF = ~(KeyT)0;
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    if (frame_flags && frame_flags[b] == 0) return;
     if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
     const int r0 = ty * WS_T, c0 = tx * WS_T;
     const int64_t fbase = (int64_t)b * H * W;
-    ws_load_tile(sL, L + fbase, r0, c0, H, W, WS_INF);
+    ws_load_tile(sK, K + fbase, r0, c0, H, W, KINF);
     ws_load_tile(sF, (const int *)F + fbase, r0, c0, H, W, 0);
     __syncthreads();
     const int px = (threadIdx.x & 15) * 4 + 1, py = (threadIdx.x >> 4) * 4 + 1;
@@ -139,9 +144,9 @@ __global__ void __launch_bounds__(256) ws_propagate_kernel(const unsigned *__res
             for (int q = 0; q < 16; ++q) {
                 int qq = pass ? 15 - q : q;
                 int i = (py + (qq >> 2)) * WS_S + px + (qq & 3);
-                if (sL[i] == WS_INF || vF[i] != 0) continue;
-                unsigned lu = sL[i - WS_S], ll = sL[i - 1], lr = sL[i + 1], ld = sL[i + WS_S];
-                unsigned m = min(min(lu, ld), min(ll, lr));
+                if ((unsigned)(sK[i] >> (8 * sizeof(KeyT) - 32)) == WS_INF || vF[i] != 0) continue;
+                KeyT lu = sK[i - WS_S], ll = sK[i - 1], lr = sK[i + 1], ld = sK[i + WS_S];
+                KeyT m = min(min(lu, ld), min(ll, lr));
                 int f = 0;
                 if (lu == m) f = vF[i - WS_S];
                 if (f == 0 && ll == m) f = vF[i - 1];
@@ -165,23 +170,27 @@ __global__ void __launch_bounds__(256) ws_propagate_kernel(const unsigned *__res
     }
 }
 
-// (3) proof check
-__global__ void __launch_bounds__(256) ws_check_kernel(const unsigned *__restrict__ L, const int *__restrict__ F,
+// (3) proof check: every neighbour whose key equals the minimum neighbour key carries the pixel's label
+template <typename KeyT>
+__global__ void __launch_bounds__(256) ws_check_kernel(const KeyT *__restrict__ K, const int *__restrict__ F,
                                                         const int *__restrict__ markers, const uint8_t *__restrict__ mask,
-                                                        int *__restrict__ tie_flags, int H, int W)
+                                                        const int *__restrict__ frame_flags, int *__restrict__ tie_flags,
+                                                        int H, int W)
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (r >= H || c >= W) return;
     const int b = blockIdx.z;
+    if (frame_flags && frame_flags[b] == 0) return;
+    const KeyT KINF = ~(KeyT)0;
     const int64_t fbase = (int64_t)b * H * W;
     const int64_t i = fbase + (int64_t)r * W + c;
-    const unsigned l = L[i];
-    if (l == WS_INF) return;                        // outside the mask or unreachable: stays 0
-    if (mask[i] != 0 && markers[i] != 0) return;    // seed: keeps its marker
-    const unsigned lu = r > 0 ? L[i - W] : WS_INF, ld = r + 1 < H ? L[i + W] : WS_INF;
-    const unsigned ll = c > 0 ? L[i - 1] : WS_INF, lr = c + 1 < W ? L[i + 1] : WS_INF;
-    const unsigned m = min(min(lu, ld), min(ll, lr));
+    const KeyT l = K[i];
+    if ((unsigned)(l >> (8 * sizeof(KeyT) - 32)) == WS_INF) return;  // outside the mask or unreachable: stays 0
+    if (mask[i] != 0 && markers[i] != 0) return;                     // seed: keeps its marker
+    const KeyT lu = r > 0 ? K[i - W] : KINF, ld = r + 1 < H ? K[i + W] : KINF;
+    const KeyT ll = c > 0 ? K[i - 1] : KINF, lr = c + 1 < W ? K[i + 1] : KINF;
+    const KeyT m = min(min(lu, ld), min(ll, lr));
     const int f = F[i];
     bool ok = f != 0;
     if (lu == m) ok = ok && F[i - W] == f;
@@ -189,6 +198,111 @@ __global__ void __launch_bounds__(256) ws_check_kernel(const unsigned *__restric
     if (lr == m) ok = ok && F[i + 1] == f;
     if (ld == m) ok = ok && F[i + W] == f;
     if (!ok && tie_flags[b] == 0) tie_flags[b] = 1;
+}
+
+// ---- second-level order for frames whose first check failed ---------------------------------------------------
+// Inside one level v = L the reference pops, in this order: every "primary entry" (a pixel of value v that was
+// pushed from a lower level, or a seed of value v) by age, each immediately followed by the whole connected lake of
+// lower-valued pixels it opens; then the value-v pixels pushed during the level ("secondary").  The age of a primary
+// entry is the pop time of its parent, whose level is K2 = min{L(n) : n neighbour, L(n) < v}; seeds have age 0.
+// Hence T is refined by (L, K2) with K2(seed) = 0, K2(entry) = that minimum, K2(secondary) = WS_SECONDARY and
+// K2(lake pixel) = min K2 over the neighbours of the same level (the earliest entry floods the whole lake).
+constexpr unsigned WS_SECONDARY = 0xFFFFFFFEu;
+
+__global__ void __launch_bounds__(256) ws_k2_init_kernel(const unsigned *__restrict__ val, const unsigned *__restrict__ L,
+                                                          const int *__restrict__ markers, const uint8_t *__restrict__ mask,
+                                                          const int *__restrict__ frame_flags, unsigned *__restrict__ K2,
+                                                          int H, int W)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= H || c >= W) return;
+    const int b = blockIdx.z;
+    if (frame_flags[b] == 0) return;
+    const int64_t i = (int64_t)b * H * W + (int64_t)r * W + c;
+    const unsigned l = L[i];
+    unsigned k = WS_INF;
+    if (l != WS_INF) {
+        if (mask[i] != 0 && markers[i] != 0) k = 0;
+        else if (val[i] == l) {
+            const unsigned lu = r > 0 ? L[i - W] : WS_INF, ld = r + 1 < H ? L[i + W] : WS_INF;
+            const unsigned ll = c > 0 ? L[i - 1] : WS_INF, lr = c + 1 < W ? L[i + 1] : WS_INF;
+            const unsigned m = min(min(lu, ld), min(ll, lr));
+            k = m < l ? max(m, 1u) : WS_SECONDARY;
+        }
+    }
+    K2[i] = k;
+}
+
+__global__ void __launch_bounds__(256) ws_k2_relax_kernel(const unsigned *__restrict__ val, const unsigned *__restrict__ L,
+                                                           unsigned *__restrict__ K2, const int *__restrict__ frame_flags,
+                                                           const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
+                                                           int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
+{
+    __shared__ unsigned sL[WS_S * WS_S];
+    __shared__ unsigned sK[WS_S * WS_S];
+    __shared__ uint8_t sLake[WS_S * WS_S];
+    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    if (frame_flags[b] == 0) return;
+    if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
+    const int r0 = ty * WS_T, c0 = tx * WS_T;
+    const int64_t fbase = (int64_t)b * H * W;
+    ws_load_tile(sL, L + fbase, r0, c0, H, W, WS_INF);
+    ws_load_tile(sK, (const unsigned *)K2 + fbase, r0, c0, H, W, WS_INF);
+    for (int i = threadIdx.x; i < WS_S * WS_S; i += 256) {
+        int lr = i / WS_S, lc = i % WS_S;
+        int r = r0 + lr - 1, c = c0 + lc - 1;
+        bool in = r >= 0 && r < H && c >= 0 && c < W;
+        unsigned l = in ? L[fbase + (int64_t)r * W + c] : WS_INF;
+        sLake[i] = in && l != WS_INF && val[fbase + (int64_t)r * W + c] < l;
+    }
+    __syncthreads();
+    const int px = (threadIdx.x & 15) * 4 + 1, py = (threadIdx.x >> 4) * 4 + 1;
+    volatile unsigned *vK = sK;
+    bool changed_any = false;
+    for (int iter = 0; iter < 100000; ++iter) {
+        bool changed = false;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int q = 0; q < 16; ++q) {
+                int qq = pass ? 15 - q : q;
+                int i = (py + (qq >> 2)) * WS_S + px + (qq & 3);
+                if (!sLake[i]) continue;
+                const unsigned l = sL[i];
+                unsigned m = vK[i];
+                if (sL[i - WS_S] == l) m = min(m, vK[i - WS_S]);
+                if (sL[i - 1] == l) m = min(m, vK[i - 1]);
+                if (sL[i + 1] == l) m = min(m, vK[i + 1]);
+                if (sL[i + WS_S] == l) m = min(m, vK[i + WS_S]);
+                if (m < vK[i]) { vK[i] = m; changed = true; }
+            }
+        }
+        if (!__syncthreads_or(changed)) break;
+        changed_any = true;
+    }
+    if (!changed_any) return;
+    for (int q = 0; q < 16; ++q) {
+        int lr = py + (q >> 2), lc = px + (q & 3);
+        int r = r0 + lr - 1, c = c0 + lc - 1;
+        if (r < H && c < W) K2[fbase + (int64_t)r * W + c] = sK[lr * WS_S + lc];
+    }
+    if (threadIdx.x == 0) {
+        ws_mark_neighbours(dirty_out, b, tx, ty, tilesX, tilesY);
+        *any_changed = 1;
+    }
+}
+
+// K64 = (L << 32) | K2 and reset of the labels to the seeds, flagged frames only
+__global__ void __launch_bounds__(256) ws_pack_reset_kernel(const unsigned *__restrict__ L, const unsigned *__restrict__ K2,
+                                                             const int *__restrict__ markers, const uint8_t *__restrict__ mask,
+                                                             const int *__restrict__ frame_flags,
+                                                             unsigned long long *__restrict__ K64, int *__restrict__ out,
+                                                             int64_t n, int64_t total)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total || frame_flags[i / n] == 0) return;
+    K64[i] = ((unsigned long long)L[i] << 32) | K2[i];
+    out[i] = mask[i] ? markers[i] : 0;
 }
 
 __global__ void ws_set_flags_kernel(int *flags, int B, int v)
@@ -289,7 +403,7 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
     if (!check_shape(B, H, W)) return 0;
     size_t n = (size_t)B * H * W;
     int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
-    return 2 * align_up(n * 4) + 2 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + align_up(sizeof(int) * B) +
+    return 2 * align_up(n * 4) + 2 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + 2 * align_up(sizeof(int) * B) +
            align_up(n * 8) + align_up(n * 4);
 }
 
@@ -311,53 +425,95 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     uint8_t *dirtyB = cv.take<uint8_t>(ntiles);
     int *changed = cv.take<int>(16);
     int *flags = cv.take<int>(B);
-    unsigned long long *heap_key = cv.take<unsigned long long>(n);
-    unsigned *heap_idx = cv.take<unsigned>(n);
+    int *flags2 = cv.take<int>(B);
+    unsigned long long *heap_key = cv.take<unsigned long long>(n);  // doubles as K64 of the second-level pass
+    unsigned *heap_idx = cv.take<unsigned>(n);                      // doubles as K2
     if (!cv.ok()) {
         set_error("watershed: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(ws_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, frame_stride, markers, mask, val, L,
+    const dim3 tgrid(tilesX, tilesY, B);
+    const dim3 pgrid((W + 63) / 64, (H + 3) / 4, B);
+    // host-driven fixed point: `launch(din, dout)` enqueues one round; polled every 4 rounds
+    auto iterate = [&](auto &&launch) -> int {
+        PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 1, ntiles, s));
+        uint8_t *din = dirtyA, *dout = dirtyB;
+        for (int round = 0;; round += 4) {
+            PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int), s));
+            for (int k = 0; k < 4; ++k) {
+                PCSEG_CHECK_HIP(hipMemsetAsync(dout, 0, ntiles, s));
+                launch(din, dout);
+                PCSEG_CHECK_LAUNCH();
+                uint8_t *t = din; din = dout; dout = t;
+            }
+            int host_changed = 0;
+            PCSEG_CHECK_HIP(hipMemcpyAsync(&host_changed, changed, sizeof(int), hipMemcpyDeviceToHost, s));
+            PCSEG_CHECK_HIP(hipStreamSynchronize(s));
+            if (!host_changed) return PCSEG_OK;
+            if (round > 4 * (tilesX * tilesY + 64) * 64) {
+                set_error("watershed: fixed point did not converge");
+                return PCSEG_ERR_HIP;
+            }
+        }
+    };
+    PCSEG_LAUNCH(ws_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, frame_stride, markers, mask, val, L,
                        out, (int64_t)H * W, (int64_t)n);
     PCSEG_CHECK_LAUNCH();
     if (mode == 1) {
-        hipLaunchKernelGGL(ws_set_flags_kernel, dim3((B + 63) / 64), dim3(64), 0, s, flags, B, 1);
+        PCSEG_LAUNCH(ws_set_flags_kernel, dim3((B + 63) / 64), dim3(64), 0, s, flags2, B, 1);
         PCSEG_CHECK_LAUNCH();
     } else {
-        dim3 tgrid(tilesX, tilesY, B);
-        for (int phase = 0; phase < 2; ++phase) {
-            PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 1, ntiles, s));
-            uint8_t *din = dirtyA, *dout = dirtyB;
-            for (int round = 0;; round += 4) {
-                PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int), s));
-                for (int k = 0; k < 4; ++k) {
-                    PCSEG_CHECK_HIP(hipMemsetAsync(dout, 0, ntiles, s));
-                    if (phase == 0)
-                        hipLaunchKernelGGL(ws_relax_kernel, tgrid, dim3(256), 0, s, val, L, din, dout, changed, H, W, tilesX, tilesY);
-                    else
-                        hipLaunchKernelGGL(ws_propagate_kernel, tgrid, dim3(256), 0, s, L, out, din, dout, changed, H, W, tilesX,
-                                           tilesY);
-                    PCSEG_CHECK_LAUNCH();
-                    uint8_t *t = din; din = dout; dout = t;
-                }
-                int host_changed = 0;
-                PCSEG_CHECK_HIP(hipMemcpyAsync(&host_changed, changed, sizeof(int), hipMemcpyDeviceToHost, s));
-                PCSEG_CHECK_HIP(hipStreamSynchronize(s));
-                if (!host_changed) break;
-                if (round > 4 * (tilesX * tilesY + 64) * 64) {
-                    set_error("watershed: relaxation did not converge");
-                    return PCSEG_ERR_HIP;
-                }
-            }
-        }
+        int rc = iterate([&](uint8_t *din, uint8_t *dout) {
+            PCSEG_LAUNCH(ws_relax_kernel, tgrid, dim3(256), 0, s, val, L, din, dout, changed, H, W, tilesX, tilesY);
+        });
+        if (rc) return rc;
+        rc = iterate([&](uint8_t *din, uint8_t *dout) {
+            PCSEG_LAUNCH(ws_propagate_kernel<unsigned>, tgrid, dim3(256), 0, s, (const unsigned *)L, out, (const int *)nullptr,
+                         din, dout, changed, H, W, tilesX, tilesY);
+        });
+        if (rc) return rc;
         PCSEG_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * B, s));
-        dim3 cgrid((W + 63) / 64, (H + 3) / 4, B);
-        hipLaunchKernelGGL(ws_check_kernel, cgrid, dim3(256), 0, s, L, out, markers, mask, flags, H, W);
+        PCSEG_CHECK_HIP(hipMemsetAsync(flags2, 0, sizeof(int) * B, s));
+        PCSEG_LAUNCH(ws_check_kernel<unsigned>, pgrid, dim3(256), 0, s, (const unsigned *)L, (const int *)out, markers, mask,
+                     (const int *)nullptr, flags, H, W);
         PCSEG_CHECK_LAUNCH();
+        int any_flag = 0;
+        {
+            // flags -> host: is the second-level pass needed at all?
+            static thread_local int host_flags[4096];
+            int nb = B < 4096 ? B : 4096;
+            PCSEG_CHECK_HIP(hipMemcpyAsync(host_flags, flags, sizeof(int) * nb, hipMemcpyDeviceToHost, s));
+            PCSEG_CHECK_HIP(hipStreamSynchronize(s));
+            for (int b = 0; b < nb; ++b) any_flag |= host_flags[b];
+            if (B > 4096) any_flag = 1;
+        }
+        if (any_flag) {
+            unsigned *K2 = heap_idx;
+            unsigned long long *K64 = heap_key;
+            PCSEG_LAUNCH(ws_k2_init_kernel, pgrid, dim3(256), 0, s, (const unsigned *)val, (const unsigned *)L, markers, mask,
+                         (const int *)flags, K2, H, W);
+            PCSEG_CHECK_LAUNCH();
+            rc = iterate([&](uint8_t *din, uint8_t *dout) {
+                PCSEG_LAUNCH(ws_k2_relax_kernel, tgrid, dim3(256), 0, s, (const unsigned *)val, (const unsigned *)L, K2,
+                             (const int *)flags, din, dout, changed, H, W, tilesX, tilesY);
+            });
+            if (rc) return rc;
+            PCSEG_LAUNCH(ws_pack_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned *)L,
+                         (const unsigned *)K2, markers, mask, (const int *)flags, K64, out, (int64_t)H * W, (int64_t)n);
+            PCSEG_CHECK_LAUNCH();
+            rc = iterate([&](uint8_t *din, uint8_t *dout) {
+                PCSEG_LAUNCH(ws_propagate_kernel<unsigned long long>, tgrid, dim3(256), 0, s, (const unsigned long long *)K64, out,
+                             (const int *)flags, din, dout, changed, H, W, tilesX, tilesY);
+            });
+            if (rc) return rc;
+            PCSEG_LAUNCH(ws_check_kernel<unsigned long long>, pgrid, dim3(256), 0, s, (const unsigned long long *)K64,
+                         (const int *)out, markers, mask, (const int *)flags, flags2, H, W);
+            PCSEG_CHECK_LAUNCH();
+        }
     }
-    if (tie_flags) PCSEG_CHECK_HIP(hipMemcpyAsync(tie_flags, flags, sizeof(int) * B, hipMemcpyDeviceToDevice, s));
+    if (tie_flags) PCSEG_CHECK_HIP(hipMemcpyAsync(tie_flags, flags2, sizeof(int) * B, hipMemcpyDeviceToDevice, s));
     if (mode != 2) {
-        hipLaunchKernelGGL(ws_exact_kernel, dim3(B), dim3(256), 0, s, val, markers, mask, out, flags, heap_key, heap_idx, H, W);
+        PCSEG_LAUNCH(ws_exact_kernel, dim3(B), dim3(256), 0, s, val, markers, mask, out, flags2, heap_key, heap_idx, H, W);
         PCSEG_CHECK_LAUNCH();
     }
     PCSEG_CHECK_HIP(hipStreamSynchronize(s));

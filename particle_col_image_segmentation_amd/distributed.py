@@ -1,0 +1,53 @@
+"""Frame-level data parallelism: one process per GPU, frames are independent units.
+
+The reference processes one image at a time in one process (tiff_analysis.py:1130-1132); frames never exchange
+state, so the path shards with NO data-path collective.  The only exchange is the all-gather of the final per-ROI
+table: row counts first, then one padded ``all_gather`` -- ``nccl`` (= RCCL over xGMI) for
+CUDA tensors, ``gloo`` for CPU tensors (tests).  Label masks stay on the rank that made them.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_frames(n_frames, rank, world_size):
+    """Round-robin frame ownership: frame i -> rank i mod world (BASELINE config 3)."""
+    return list(range(rank, n_frames, world_size))
+
+
+def all_gather_table(table, group=None, sort_cols=(0, 1)):
+    """Gather (rows_r, cols) float64 tables from every rank into one table, sorted by the key columns
+    (frame, label) so that the result does not depend on the number of ranks."""
+    if not dist.is_available() or not dist.is_initialized():
+        out = table
+    else:
+        world = dist.get_world_size(group)
+        dev = table.device
+        n = torch.tensor([table.shape[0]], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(counts, n, group=group)
+        counts = [int(c.item()) for c in counts]
+        cols = table.shape[1]
+        pad = torch.zeros((max(max(counts), 1), cols), dtype=table.dtype, device=dev)
+        pad[: table.shape[0]] = table
+        parts = [torch.zeros_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        out = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+    if out.shape[0] and sort_cols:
+        key = out[:, sort_cols[0]].to(torch.float64)
+        for c in sort_cols[1:]:
+            key = key * (float(out[:, c].max().item()) + 1.0) + out[:, c].to(torch.float64)
+        out = out[torch.argsort(key)]
+    return out
+
+
+def gather_tables(tables, device=None, group=None):
+    """all-gather every table of FramePipeline.tables() (numpy in, numpy out)."""
+    out = dict(tables)
+    for name in ("cells", "rois", "frames", "groups"):
+        t = torch.from_numpy(np.ascontiguousarray(tables[name]))
+        if device is not None:
+            t = t.to(device)
+        sort_cols = (0,) if name == "frames" else ((0, 1, 2) if name == "groups" else (0, 1))
+        out[name] = all_gather_table(t, group, sort_cols).cpu().numpy()
+    return out

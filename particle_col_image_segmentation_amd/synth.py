@@ -97,32 +97,34 @@ def class_map_from_stack(stack):
     return (np.argmax(stack, axis=-3) + 1).astype(np.uint8)
 
 
-def gen_batch_torch(base_seed, B, H, W, device, ties=False):
-    """Device twin of :func:`gen_batch` (same model, torch random stream)."""
+def gen_batch_torch(base_seed, B, H, W, device, ties=False, chunk=32):
+    """Device twin of :func:`gen_batch` (same model, torch random stream).
+
+    The signed distance to the nearest disc edge is a chunked min over discs, entirely on the device, so that a
+    64 x 1024 x 1024 x 5 batch is built in about a second and never crosses PCIe."""
     import torch
 
     g = torch.Generator(device="cpu")
     out = torch.empty((B, N_PLANES, H, W), dtype=torch.float32, device=device)
-    ar_y = torch.arange(H, dtype=torch.float32, device=device)[:, None]
-    ar_x = torch.arange(W, dtype=torch.float32, device=device)[None, :]
-    sd_p = torch.sqrt((ar_y - H / 2.0) ** 2 + (ar_x - W / 2.0) ** 2) - 0.3 * H
+    ar_y = torch.arange(H, dtype=torch.float32, device=device)[None, :, None]
+    ar_x = torch.arange(W, dtype=torch.float32, device=device)[None, None, :]
+    sd_p = torch.sqrt((ar_y[0] - H / 2.0) ** 2 + (ar_x[0] - W / 2.0) ** 2) - 0.3 * H
     m_p = torch.clamp(0.5 - sd_p / 2.0, 0.0, 1.0)
     margin = 12.0
+    n = max(1, (H * W) // 1000)
     for b in range(B):
         g.manual_seed(int(base_seed) + b)
-        n = max(1, (H * W) // 1000)
-        cy = (10.0 + torch.rand(n, generator=g) * (H - 20.0)).tolist()
-        cx = (10.0 + torch.rand(n, generator=g) * (W - 20.0)).tolist()
-        rad = torch.randint(3, 12, (n,), generator=g).tolist()
-        typ = torch.randint(0, 2, (n,), generator=g).tolist()
+        cy = (10.0 + torch.rand(n, generator=g) * (H - 20.0)).to(device)
+        cx = (10.0 + torch.rand(n, generator=g) * (W - 20.0)).to(device)
+        rad = torch.randint(3, 12, (n,), generator=g).to(device=device, dtype=torch.float32)
+        typ = torch.randint(0, 2, (n,), generator=g).to(device)
         sd = torch.full((2, H, W), margin, dtype=torch.float32, device=device)
-        for y, x, r, t in zip(cy, cx, rad, typ):
-            r0 = int(max(0, y - r - margin))
-            r1 = int(min(H, y + r + margin + 2))
-            c0 = int(max(0, x - r - margin))
-            c1 = int(min(W, x + r + margin + 2))
-            d = torch.sqrt((ar_y[r0:r1] - y) ** 2 + (ar_x[:, c0:c1] - x) ** 2) - r
-            sd[t, r0:r1, c0:c1] = torch.minimum(sd[t, r0:r1, c0:c1], d)
+        for t in range(2):
+            idx = torch.nonzero(typ == t)[:, 0]
+            for i in range(0, idx.numel(), chunk):
+                j = idx[i:i + chunk]
+                d = torch.sqrt((ar_y - cy[j, None, None]) ** 2 + (ar_x - cx[j, None, None]) ** 2) - rad[j, None, None]
+                sd[t] = torch.minimum(sd[t], d.amin(dim=0))
         dg = torch.Generator(device=device)
         dg.manual_seed(int(base_seed) + b)
         logits = 0.1 * torch.rand((N_PLANES, H, W), generator=dg, device=device)

@@ -1,0 +1,69 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard frames round-robin and all-gather their ROI tables; the
+gathered table must equal the single-process table whatever the number of ranks."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from particle_col_image_segmentation_amd.distributed import all_gather_table, gather_tables, shard_frames
+
+
+def _fake_tables(frames):
+    """Deterministic per-frame tables (what FramePipeline.tables would give), built on CPU."""
+    rng_rows = []
+    roi_rows = []
+    frame_rows = []
+    for f in frames:
+        rng = np.random.default_rng(1000 + f)
+        n = 3 + f % 4
+        for l in range(n):
+            rng_rows.append([f, l + 1] + list(rng.random(5)))
+        for l in range(n + 2):
+            roi_rows.append([f, l + 1] + list(rng.random(3)))
+        frame_rows.append([f, n, n + 2])
+    return {"cells": np.array(rng_rows).reshape(-1, 7), "rois": np.array(roi_rows).reshape(-1, 5),
+            "frames": np.array(frame_rows, np.float64).reshape(-1, 3), "groups": np.zeros((0, 11))}
+
+
+def _worker(rank, world, port, n_frames, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_frames(n_frames, rank, world)
+    gathered = gather_tables(_fake_tables(mine))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "g%d.npz" % world), **{k: v for k, v in gathered.items() if isinstance(v, np.ndarray)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_frames_round_robin():
+    assert shard_frames(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((shard_frames(1000, r, 8) for r in range(8)), [])) == list(range(1000))
+
+
+def test_single_process_gather_is_identity_sorted():
+    t = torch.tensor([[2.0, 1.0, 5.0], [0.0, 2.0, 6.0], [0.0, 1.0, 7.0]], dtype=torch.float64)
+    out = all_gather_table(t)
+    assert out[:, :2].tolist() == [[0.0, 1.0], [0.0, 2.0], [2.0, 1.0]]
+
+
+def test_two_and_three_rank_gather_equals_single(tmp_path):
+    n_frames = 11
+    single = _fake_tables(range(n_frames))
+    for world in (2, 3):
+        mp.spawn(_worker, args=(world, _free_port(), n_frames, str(tmp_path)), nprocs=world, join=True)
+        g = np.load(str(tmp_path / ("g%d.npz" % world)))
+        for name in ("cells", "rois", "frames"):
+            np.testing.assert_array_equal(g[name], single[name])
