@@ -59,10 +59,15 @@ __device__ __forceinline__ void unite_lds(int *par, int a, int b)
 }
 
 // ---- global union-find (parents only ever decrease; stale reads cost iterations, never correctness)
-__device__ __forceinline__ int find_glb(const int *par, int x)
+__device__ __forceinline__ int find_glb(int *par, int x)
 {
+    // path halving: re-pointing x at its grandparent is always valid (any ancestor is) and races are benign
     int p;
-    while ((p = ld_agent(par + x)) != x) x = p;
+    while ((p = ld_agent(par + x)) != x) {
+        int g = ld_agent(par + p);
+        if (g != p) __hip_atomic_store(par + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = g;
+    }
     return x;
 }
 __device__ __forceinline__ void unite_glb(int *par, int a, int b)
@@ -136,12 +141,19 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(KeyFn keyfn, int *__res
     const int p = r * W + c;
     const int k = keyfn(fbase + p);
     if (k == 0) return;
-    if (left && keyfn(fbase + p - 1) == k) unite_glb(par, p, p - 1);
+    // the same "implied link" rule as inside a tile: a link is skipped when the two pixels are already joined through
+    // a third one whose links are made elsewhere (run links inside a tile row, vertical links of the left neighbour)
+    const bool w_same = c > 0 && keyfn(fbase + p - 1) == k;
+    const bool n_same = r > 0 && keyfn(fbase + p - W) == k;
+    const bool nw_same = r > 0 && c > 0 && keyfn(fbase + p - W - 1) == k;
+    // (at a tile corner both the W and the N link cross tiles and would justify each other: keep both there)
+    const bool corner = top && left;
+    if (left && w_same && (corner || !(n_same && nw_same))) unite_glb(par, p, p - 1);
     if (r > 0) {
-        if (top && keyfn(fbase + p - W) == k) unite_glb(par, p, p - W);
+        if (top && n_same && (corner || !(w_same && nw_same))) unite_glb(par, p, p - W);
         if (CONN8) {
-            if (c > 0 && (top || left) && keyfn(fbase + p - W - 1) == k) unite_glb(par, p, p - W - 1);
-            if (c + 1 < W && (top || right) && keyfn(fbase + p - W + 1) == k) unite_glb(par, p, p - W + 1);
+            if ((top || left) && nw_same && !n_same && !w_same) unite_glb(par, p, p - W - 1);
+            if (c + 1 < W && (top || right) && !n_same && keyfn(fbase + p - W + 1) == k) unite_glb(par, p, p - W + 1);
         }
     }
 }

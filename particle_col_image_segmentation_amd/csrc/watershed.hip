@@ -23,6 +23,8 @@ namespace pcseg {
 
 constexpr int WS_T = 64;           // tile edge
 constexpr int WS_S = WS_T + 2;     // with halo
+constexpr int WS_P = 67;           // LDS row pitch in elements (odd: row-per-lane sweeps are bank-conflict free)
+constexpr int WS_N = WS_S * WS_P;  // LDS elements per tile array
 constexpr unsigned WS_INF = 0xFFFFFFFFu;
 
 // order-preserving key of a float32 (the reference compares float64(image)); -0.0 == +0.0
@@ -55,7 +57,36 @@ __device__ __forceinline__ void ws_load_tile(T *s, const T *__restrict__ g, int 
     for (int i = threadIdx.x; i < WS_S * WS_S; i += 256) {
         int lr = i / WS_S, lc = i % WS_S;
         int r = r0 + lr - 1, c = c0 + lc - 1;
-        s[i] = (r >= 0 && r < H && c >= 0 && c < W) ? g[(int64_t)r * W + c] : fill;
+        s[lr * WS_P + lc] = (r >= 0 && r < H && c >= 0 && c < W) ? g[(int64_t)r * W + c] : fill;
+    }
+}
+
+// The tile fixed points below are run as DIRECTIONAL SWEEPS: wave 0 sweeps the 64 rows left->right (one row per
+// lane), wave 1 right->left, wave 2 the 64 columns top->bottom, wave 3 bottom->top, all at once.  Every update is
+// monotone (min / 0->label), so concurrent sweeps may read each other's half-finished values: a stale read only
+// costs another outer iteration.  One sweep carries information across the whole tile, so the number of outer
+// iterations is the number of direction changes of the dependency paths, not their length.
+struct SweepLine {
+    int start, step;  // LDS index of the halo element in front of the line, and the index step along the line
+};
+__device__ __forceinline__ SweepLine ws_line()
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    SweepLine s;
+    if (w == 0) { s.start = (lane + 1) * WS_P; s.step = 1; }
+    else if (w == 1) { s.start = (lane + 1) * WS_P + WS_S - 1; s.step = -1; }
+    else if (w == 2) { s.start = lane + 1; s.step = WS_P; }
+    else { s.start = (WS_S - 1) * WS_P + lane + 1; s.step = -WS_P; }
+    return s;
+}
+
+template <typename T>
+__device__ __forceinline__ void ws_store_tile(const T *s, T *__restrict__ g, int r0, int c0, int H, int W)
+{
+    for (int i = threadIdx.x; i < WS_T * WS_T; i += 256) {
+        int lr = i / WS_T, lc = i % WS_T;
+        int r = r0 + lr, c = c0 + lc;
+        if (r < H && c < W) g[(int64_t)r * W + c] = s[(lr + 1) * WS_P + lc + 1];
     }
 }
 
@@ -73,8 +104,8 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restric
                                                         const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
                                                         int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
 {
-    __shared__ unsigned sL[WS_S * WS_S];
-    __shared__ unsigned sV[WS_S * WS_S];
+    __shared__ unsigned sL[WS_N];
+    __shared__ unsigned sV[WS_N];
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
     if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
     const int r0 = ty * WS_T, c0 = tx * WS_T;
@@ -82,33 +113,25 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restric
     ws_load_tile(sL, L + fbase, r0, c0, H, W, WS_INF);
     ws_load_tile(sV, val + fbase, r0, c0, H, W, WS_INF);
     __syncthreads();
-    const int px = (threadIdx.x & 15) * 4 + 1, py = (threadIdx.x >> 4) * 4 + 1;
-    volatile unsigned *vL = sL;
+    const SweepLine ln = ws_line();
     bool changed_any = false;
     for (int iter = 0; iter < 100000; ++iter) {
         bool changed = false;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int q = 0; q < 16; ++q) {
-                int qq = pass ? 15 - q : q;
-                int i = (py + (qq >> 2)) * WS_S + px + (qq & 3);
-                unsigned v = sV[i];
-                if (v == WS_INF) continue;
-                unsigned cur = vL[i];
-                unsigned m = min(min(vL[i - WS_S], vL[i + WS_S]), min(vL[i - 1], vL[i + 1]));
-                unsigned cand = max(v, m);
-                if (cand < cur) { vL[i] = cand; changed = true; }
-            }
+        unsigned prev = sL[ln.start];
+        int i = ln.start;
+#pragma unroll 8
+        for (int k = 0; k < WS_T; ++k) {
+            i += ln.step;
+            unsigned cur = sL[i];
+            unsigned cand = max(sV[i], prev);
+            if (cand < cur) { sL[i] = cand; cur = cand; changed = true; }
+            prev = cur;
         }
         if (!__syncthreads_or(changed)) break;
         changed_any = true;
     }
     if (!changed_any) return;
-    for (int q = 0; q < 16; ++q) {
-        int lr = py + (q >> 2), lc = px + (q & 3);
-        int r = r0 + lr - 1, c = c0 + lc - 1;
-        if (r < H && c < W) L[fbase + (int64_t)r * W + c] = sL[lr * WS_S + lc];
-    }
+    ws_store_tile(sL, L + fbase, r0, c0, H, W);
     if (threadIdx.x == 0) {
         ws_mark_neighbours(dirty_out, b, tx, ty, tilesX, tilesY);
         *any_changed = 1;
@@ -123,8 +146,9 @@ __global__ void __launch_bounds__(256) ws_propagate_kernel(const KeyT *__restric
                                                             const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
                                                             int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
 {
-    __shared__ KeyT sK[WS_S * WS_S];
-    __shared__ int sF[WS_S * WS_S];
+    __shared__ KeyT sK[WS_N];
+    __shared__ int sF[WS_N];
+    __shared__ uint8_t sC[WS_N];  // which neighbours hold the minimum neighbour key: bit0 up, 1 left, 2 right, 3 down
     const KeyT KINF = ~(KeyT)0;
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
     if (frame_flags && frame_flags[b] == 0) return;
@@ -134,36 +158,38 @@ __global__ void __launch_bounds__(256) ws_propagate_kernel(const KeyT *__restric
     ws_load_tile(sK, K + fbase, r0, c0, H, W, KINF);
     ws_load_tile(sF, (const int *)F + fbase, r0, c0, H, W, 0);
     __syncthreads();
-    const int px = (threadIdx.x & 15) * 4 + 1, py = (threadIdx.x >> 4) * 4 + 1;
-    volatile int *vF = sF;
+    for (int t = threadIdx.x; t < WS_T * WS_T; t += 256) {
+        int i = (t / WS_T + 1) * WS_P + t % WS_T + 1;
+        uint8_t m8 = 0;
+        if ((unsigned)(sK[i] >> (8 * sizeof(KeyT) - 32)) != WS_INF) {
+            KeyT lu = sK[i - WS_P], ll = sK[i - 1], lr = sK[i + 1], ld = sK[i + WS_P];
+            KeyT m = min(min(lu, ld), min(ll, lr));
+            m8 = (lu == m ? 1 : 0) | (ll == m ? 2 : 0) | (lr == m ? 4 : 0) | (ld == m ? 8 : 0);
+        }
+        sC[i] = m8;
+    }
+    __syncthreads();
+    const SweepLine ln = ws_line();
+    // the neighbour BEHIND the sweep direction: left for w0, right for w1, up for w2, down for w3
+    const int w = threadIdx.x >> 6;
+    const uint8_t behind = w == 0 ? 2 : (w == 1 ? 4 : (w == 2 ? 1 : 8));
     bool changed_any = false;
     for (int iter = 0; iter < 100000; ++iter) {
         bool changed = false;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int q = 0; q < 16; ++q) {
-                int qq = pass ? 15 - q : q;
-                int i = (py + (qq >> 2)) * WS_S + px + (qq & 3);
-                if ((unsigned)(sK[i] >> (8 * sizeof(KeyT) - 32)) == WS_INF || vF[i] != 0) continue;
-                KeyT lu = sK[i - WS_S], ll = sK[i - 1], lr = sK[i + 1], ld = sK[i + WS_S];
-                KeyT m = min(min(lu, ld), min(ll, lr));
-                int f = 0;
-                if (lu == m) f = vF[i - WS_S];
-                if (f == 0 && ll == m) f = vF[i - 1];
-                if (f == 0 && lr == m) f = vF[i + 1];
-                if (f == 0 && ld == m) f = vF[i + WS_S];
-                if (f != 0) { vF[i] = f; changed = true; }
-            }
+        int prev = sF[ln.start];
+        int i = ln.start;
+#pragma unroll 8
+        for (int k = 0; k < WS_T; ++k) {
+            i += ln.step;
+            int f = sF[i];
+            if (f == 0 && prev != 0 && (sC[i] & behind)) { sF[i] = prev; f = prev; changed = true; }
+            prev = f;
         }
         if (!__syncthreads_or(changed)) break;
         changed_any = true;
     }
     if (!changed_any) return;
-    for (int q = 0; q < 16; ++q) {
-        int lr = py + (q >> 2), lc = px + (q & 3);
-        int r = r0 + lr - 1, c = c0 + lc - 1;
-        if (r < H && c < W) F[fbase + (int64_t)r * W + c] = sF[lr * WS_S + lc];
-    }
+    ws_store_tile(sF, F + fbase, r0, c0, H, W);
     if (threadIdx.x == 0) {
         ws_mark_neighbours(dirty_out, b, tx, ty, tilesX, tilesY);
         *any_changed = 1;
@@ -239,9 +265,9 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const unsigned *__rest
                                                            const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
                                                            int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
 {
-    __shared__ unsigned sL[WS_S * WS_S];
-    __shared__ unsigned sK[WS_S * WS_S];
-    __shared__ uint8_t sLake[WS_S * WS_S];
+    __shared__ unsigned sL[WS_N];
+    __shared__ unsigned sK[WS_N];
+    __shared__ uint8_t sLake[WS_N];
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
     if (frame_flags[b] == 0) return;
     if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
@@ -254,38 +280,28 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const unsigned *__rest
         int r = r0 + lr - 1, c = c0 + lc - 1;
         bool in = r >= 0 && r < H && c >= 0 && c < W;
         unsigned l = in ? L[fbase + (int64_t)r * W + c] : WS_INF;
-        sLake[i] = in && l != WS_INF && val[fbase + (int64_t)r * W + c] < l;
+        sLake[lr * WS_P + lc] = in && l != WS_INF && val[fbase + (int64_t)r * W + c] < l;
     }
     __syncthreads();
-    const int px = (threadIdx.x & 15) * 4 + 1, py = (threadIdx.x >> 4) * 4 + 1;
-    volatile unsigned *vK = sK;
+    const SweepLine ln = ws_line();
     bool changed_any = false;
     for (int iter = 0; iter < 100000; ++iter) {
         bool changed = false;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int q = 0; q < 16; ++q) {
-                int qq = pass ? 15 - q : q;
-                int i = (py + (qq >> 2)) * WS_S + px + (qq & 3);
-                if (!sLake[i]) continue;
-                const unsigned l = sL[i];
-                unsigned m = vK[i];
-                if (sL[i - WS_S] == l) m = min(m, vK[i - WS_S]);
-                if (sL[i - 1] == l) m = min(m, vK[i - 1]);
-                if (sL[i + 1] == l) m = min(m, vK[i + 1]);
-                if (sL[i + WS_S] == l) m = min(m, vK[i + WS_S]);
-                if (m < vK[i]) { vK[i] = m; changed = true; }
-            }
+        unsigned prevK = sK[ln.start], prevL = sL[ln.start];
+        int i = ln.start;
+#pragma unroll 8
+        for (int k = 0; k < WS_T; ++k) {
+            i += ln.step;
+            unsigned cur = sK[i], l = sL[i];
+            if (sLake[i] && l == prevL && prevK < cur) { sK[i] = prevK; cur = prevK; changed = true; }
+            prevK = cur;
+            prevL = l;
         }
         if (!__syncthreads_or(changed)) break;
         changed_any = true;
     }
     if (!changed_any) return;
-    for (int q = 0; q < 16; ++q) {
-        int lr = py + (q >> 2), lc = px + (q & 3);
-        int r = r0 + lr - 1, c = c0 + lc - 1;
-        if (r < H && c < W) K2[fbase + (int64_t)r * W + c] = sK[lr * WS_S + lc];
-    }
+    ws_store_tile(sK, K2 + fbase, r0, c0, H, W);
     if (threadIdx.x == 0) {
         ws_mark_neighbours(dirty_out, b, tx, ty, tilesX, tilesY);
         *any_changed = 1;
