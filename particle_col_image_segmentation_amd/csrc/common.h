@@ -93,4 +93,49 @@ __device__ __forceinline__ unsigned ld_agent(const unsigned *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- LDS union-find
+__device__ __forceinline__ int find_lds(volatile int *par, int x)
+{
+    int p;
+    while ((p = par[x]) != x) x = p;
+    return x;
+}
+__device__ __forceinline__ void unite_lds(int *par, int a, int b)
+{
+    for (;;) {
+        a = find_lds(par, a);
+        b = find_lds(par, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(&par[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// ---- global union-find (parents only ever decrease; stale reads cost iterations, never correctness)
+__device__ __forceinline__ int find_glb(int *par, int x)
+{
+    // path halving: re-pointing x at its grandparent is always valid (any ancestor is) and races are benign
+    int p;
+    while ((p = ld_agent(par + x)) != x) {
+        int g = ld_agent(par + p);
+        if (g != p) __hip_atomic_store(par + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = g;
+    }
+    return x;
+}
+__device__ __forceinline__ void unite_glb(int *par, int a, int b)
+{
+    for (;;) {
+        a = find_glb(par, a);
+        b = find_glb(par, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(par + a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
 }  // namespace pcseg

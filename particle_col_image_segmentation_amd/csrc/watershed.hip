@@ -17,6 +17,8 @@
 //   * frames that fail the check (equal-valued bottlenecks or seeds between two
 //     basins -- ubiquitous in quantised probability maps) are recomputed by an
 //     exact emulation of the reference's binary heap, one workgroup per frame.
+#include <type_traits>
+
 #include "common.h"
 
 namespace pcseg {
@@ -194,6 +196,139 @@ __global__ void __launch_bounds__(256) ws_propagate_kernel(const KeyT *__restric
         ws_mark_neighbours(dirty_out, b, tx, ty, tilesX, tilesY);
         *any_changed = 1;
     }
+}
+
+// (2') label assignment by union-find instead of wavefronts: every non-seed reachable pixel is united with ALL its
+// neighbours that hold the minimum neighbour key.  If no pixel has minimum-key neighbours in two basins (the proof
+// check's premise) the components are exactly the basins, each holding the seeds of one marker; a component that
+// holds two different marker ids flags the frame instead.  One LDS tile pass + one border pass + flatten, like A2.
+constexpr int UF_TW = 64, UF_TH = 32, UF_SW = UF_TW + 2, UF_SH = UF_TH + 2;
+
+template <typename KeyT>
+__global__ void __launch_bounds__(256) ws_uf_tile_kernel(const KeyT *__restrict__ K, const int *__restrict__ F,
+                                                          const int *__restrict__ frame_flags, int *__restrict__ parent,
+                                                          int H, int W)
+{
+    __shared__ KeyT sK[UF_SH * UF_SW];
+    __shared__ int par[UF_TH * UF_TW];
+    const KeyT KINF = ~(KeyT)0;
+    const int b = blockIdx.z;
+    if (frame_flags && frame_flags[b] == 0) return;
+    const int r0 = blockIdx.y * UF_TH, c0 = blockIdx.x * UF_TW;
+    const int64_t fbase = (int64_t)b * H * W;
+    for (int i = threadIdx.x; i < UF_SH * UF_SW; i += 256) {
+        int r = r0 + i / UF_SW - 1, c = c0 + i % UF_SW - 1;
+        sK[i] = (r >= 0 && r < H && c >= 0 && c < W) ? K[fbase + (int64_t)r * W + c] : KINF;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < UF_TH * UF_TW; t += 256) {
+        int i = (t / UF_TW + 1) * UF_SW + t % UF_TW + 1;
+        par[t] = ((unsigned)(sK[i] >> (8 * sizeof(KeyT) - 32)) == WS_INF) ? -1 : t;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < UF_TH * UF_TW; t += 256) {
+        if (par[t] < 0) continue;
+        const int lr = t / UF_TW, lc = t % UF_TW;
+        const int r = r0 + lr, c = c0 + lc;
+        if (r >= H || c >= W) continue;
+        if (F[fbase + (int64_t)r * W + c] != 0) continue;  // seeds take no label from neighbours
+        const int i = (lr + 1) * UF_SW + lc + 1;
+        const KeyT ku = sK[i - UF_SW], kl = sK[i - 1], kr = sK[i + 1], kd = sK[i + UF_SW];
+        const KeyT m = min(min(ku, kd), min(kl, kr));
+        if (m == KINF) continue;
+        if (ku == m && lr > 0) unite_lds(par, t, t - UF_TW);
+        if (kl == m && lc > 0) unite_lds(par, t, t - 1);
+        if (kr == m && lc < UF_TW - 1) unite_lds(par, t, t + 1);
+        if (kd == m && lr < UF_TH - 1) unite_lds(par, t, t + UF_TW);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < UF_TH * UF_TW; t += 256) {
+        const int r = r0 + t / UF_TW, c = c0 + t % UF_TW;
+        if (r >= H || c >= W) continue;
+        int v = -1;
+        if (par[t] >= 0) {
+            int root = find_lds(par, t);
+            v = (r0 + root / UF_TW) * W + c0 + root % UF_TW;
+        }
+        parent[fbase + (int64_t)r * W + c] = v;
+    }
+}
+
+// is q one of the minimum-key neighbours of the non-seed pixel p?  (keys read from global memory)
+template <typename KeyT>
+__device__ __forceinline__ bool ws_is_min_nbr(const KeyT *__restrict__ K, const int *__restrict__ F, int64_t fbase, int pr,
+                                              int pc, int qr, int qc, int H, int W)
+{
+    const KeyT KINF = ~(KeyT)0;
+    const int64_t p = fbase + (int64_t)pr * W + pc;
+    if ((unsigned)(K[p] >> (8 * sizeof(KeyT) - 32)) == WS_INF || F[p] != 0) return false;
+    const KeyT ku = pr > 0 ? K[p - W] : KINF, kd = pr + 1 < H ? K[p + W] : KINF;
+    const KeyT kl = pc > 0 ? K[p - 1] : KINF, kr = pc + 1 < W ? K[p + 1] : KINF;
+    const KeyT m = min(min(ku, kd), min(kl, kr));
+    if (m == KINF) return false;
+    return K[fbase + (int64_t)qr * W + qc] == m;
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(256) ws_uf_border_kernel(const KeyT *__restrict__ K, const int *__restrict__ F,
+                                                            const int *__restrict__ frame_flags, int *__restrict__ parent,
+                                                            int H, int W)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= H || c >= W) return;
+    const int b = blockIdx.z;
+    if (frame_flags && frame_flags[b] == 0) return;
+    const bool top = (r % UF_TH) == 0 && r > 0;
+    const bool left = (c % UF_TW) == 0 && c > 0;
+    if (!top && !left) return;
+    const int64_t fbase = (int64_t)b * H * W;
+    int *par = parent + fbase;
+    const int p = r * W + c;
+    if (top && (ws_is_min_nbr(K, F, fbase, r, c, r - 1, c, H, W) || ws_is_min_nbr(K, F, fbase, r - 1, c, r, c, H, W)))
+        unite_glb(par, p, p - W);
+    if (left && (ws_is_min_nbr(K, F, fbase, r, c, r, c - 1, H, W) || ws_is_min_nbr(K, F, fbase, r, c - 1, r, c, H, W)))
+        unite_glb(par, p, p - 1);
+}
+
+// flatten + seeds publish their marker id at the root: hi = max id, nlo = max (INT_MAX - id)  (both start at 0)
+__global__ void __launch_bounds__(256) ws_uf_seed_kernel(int *__restrict__ parent, const int *__restrict__ F,
+                                                          const int *__restrict__ frame_flags, int *__restrict__ hi,
+                                                          int *__restrict__ nlo, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= n || (frame_flags && frame_flags[b] == 0)) return;
+    int *par = parent + (int64_t)b * n;
+    int p = par[i];
+    if (p < 0) return;
+    int x = p, q;
+    while ((q = par[x]) != x) x = q;
+    if (x != p) par[i] = x;
+    const int f = F[(int64_t)b * n + i];
+    if (f != 0) {
+        atomicMax(&hi[(int64_t)b * n + x], f);
+        atomicMax(&nlo[(int64_t)b * n + x], 0x7FFFFFFF - f);
+    }
+}
+
+__global__ void __launch_bounds__(256) ws_uf_assign_kernel(const int *__restrict__ parent, int *__restrict__ F,
+                                                            const int *__restrict__ frame_flags, const int *__restrict__ hi,
+                                                            const int *__restrict__ nlo, int *__restrict__ tie_flags, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= n || (frame_flags && frame_flags[b] == 0)) return;
+    const int64_t g = (int64_t)b * n + i;
+    int p = parent[g];
+    if (p < 0) return;
+    // parents were flattened by the seed pass except where a later pixel re-pointed: one more hop is enough
+    const int *par = parent + (int64_t)b * n;
+    int x = p, q;
+    while ((q = par[x]) != x) x = q;
+    const int h = hi[(int64_t)b * n + x], l = 0x7FFFFFFF - nlo[(int64_t)b * n + x];
+    if (h != 0 && h != l && tie_flags[b] == 0) tie_flags[b] = 1;  // two markers in one component: not provable
+    if (F[g] == 0) F[g] = h;
 }
 
 // (3) proof check: every neighbour whose key equals the minimum neighbour key carries the pixel's label
@@ -419,7 +554,7 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
     if (!check_shape(B, H, W)) return 0;
     size_t n = (size_t)B * H * W;
     int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
-    return 2 * align_up(n * 4) + 2 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + 2 * align_up(sizeof(int) * B) +
+    return 5 * align_up(n * 4) + 2 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + 2 * align_up(sizeof(int) * B) +
            align_up(n * 8) + align_up(n * 4);
 }
 
@@ -444,6 +579,9 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     int *flags2 = cv.take<int>(B);
     unsigned long long *heap_key = cv.take<unsigned long long>(n);  // doubles as K64 of the second-level pass
     unsigned *heap_idx = cv.take<unsigned>(n);                      // doubles as K2
+    int *uf_parent = cv.take<int>(n);
+    int *uf_hi = cv.take<int>(n);
+    int *uf_nlo = cv.take<int>(n);
     if (!cv.ok()) {
         set_error("watershed: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
@@ -483,13 +621,31 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             PCSEG_LAUNCH(ws_relax_kernel, tgrid, dim3(256), 0, s, val, L, din, dout, changed, H, W, tilesX, tilesY);
         });
         if (rc) return rc;
-        rc = iterate([&](uint8_t *din, uint8_t *dout) {
-            PCSEG_LAUNCH(ws_propagate_kernel<unsigned>, tgrid, dim3(256), 0, s, (const unsigned *)L, out, (const int *)nullptr,
-                         din, dout, changed, H, W, tilesX, tilesY);
-        });
-        if (rc) return rc;
+        const dim3 ugrid((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B);
+        const dim3 lgrid((unsigned)(((size_t)H * W + 255) / 256), B);
+        // label assignment = union-find over "minimum-key neighbour" links (flags the frame on a two-marker component)
+        auto assign_labels = [&](auto *keys, const int *frame_flags, int *out_flags) -> int {
+            using KeyT = std::remove_const_t<std::remove_pointer_t<decltype(keys)>>;
+            PCSEG_CHECK_HIP(hipMemsetAsync(uf_hi, 0, sizeof(int) * n, s));
+            PCSEG_CHECK_HIP(hipMemsetAsync(uf_nlo, 0, sizeof(int) * n, s));
+            PCSEG_LAUNCH(ws_uf_tile_kernel<KeyT>, ugrid, dim3(256), 0, s, (const KeyT *)keys, (const int *)out, frame_flags,
+                         uf_parent, H, W);
+            PCSEG_CHECK_LAUNCH();
+            PCSEG_LAUNCH(ws_uf_border_kernel<KeyT>, pgrid, dim3(256), 0, s, (const KeyT *)keys, (const int *)out, frame_flags,
+                         uf_parent, H, W);
+            PCSEG_CHECK_LAUNCH();
+            PCSEG_LAUNCH(ws_uf_seed_kernel, lgrid, dim3(256), 0, s, uf_parent, (const int *)out, frame_flags, uf_hi, uf_nlo,
+                         (int64_t)H * W);
+            PCSEG_CHECK_LAUNCH();
+            PCSEG_LAUNCH(ws_uf_assign_kernel, lgrid, dim3(256), 0, s, (const int *)uf_parent, out, frame_flags,
+                         (const int *)uf_hi, (const int *)uf_nlo, out_flags, (int64_t)H * W);
+            PCSEG_CHECK_LAUNCH();
+            return PCSEG_OK;
+        };
         PCSEG_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * B, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(flags2, 0, sizeof(int) * B, s));
+        rc = assign_labels((const unsigned *)L, (const int *)nullptr, flags);
+        if (rc) return rc;
         PCSEG_LAUNCH(ws_check_kernel<unsigned>, pgrid, dim3(256), 0, s, (const unsigned *)L, (const int *)out, markers, mask,
                      (const int *)nullptr, flags, H, W);
         PCSEG_CHECK_LAUNCH();
@@ -517,10 +673,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             PCSEG_LAUNCH(ws_pack_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned *)L,
                          (const unsigned *)K2, markers, mask, (const int *)flags, K64, out, (int64_t)H * W, (int64_t)n);
             PCSEG_CHECK_LAUNCH();
-            rc = iterate([&](uint8_t *din, uint8_t *dout) {
-                PCSEG_LAUNCH(ws_propagate_kernel<unsigned long long>, tgrid, dim3(256), 0, s, (const unsigned long long *)K64, out,
-                             (const int *)flags, din, dout, changed, H, W, tilesX, tilesY);
-            });
+            rc = assign_labels((const unsigned long long *)K64, (const int *)flags, flags2);
             if (rc) return rc;
             PCSEG_LAUNCH(ws_check_kernel<unsigned long long>, pgrid, dim3(256), 0, s, (const unsigned long long *)K64,
                          (const int *)out, markers, mask, (const int *)flags, flags2, H, W);
