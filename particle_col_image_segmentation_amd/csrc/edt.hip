@@ -182,17 +182,22 @@ __global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict
         } else {
             unsigned g0 = gr[c];
             best = g0 == G_INF ? (1ll << 40) : (long long)g0 * g0;
-            for (int k = 1; k <= kmax && (long long)k * k < best; ++k) {
-                long long kk = (long long)k * k;
-                if (c - k >= 0) {
-                    unsigned gl = gr[c - k];
-                    if (gl != G_INF) best = min(best, (long long)gl * gl + kk);
-                }
-                if (c + k < W) {
-                    unsigned gq = gr[c + k];
-                    if (gq != G_INF) best = min(best, (long long)gq * gq + kk);
-                }
+            // four offsets per trip: the 8 LDS reads are issued together; offsets past the exit point are still true
+            // candidates (g^2 + k^2 of a real pixel), so the minimum stays exact
+            for (int k = 1; k <= kmax && (long long)k * k < best; k += 4) {
                 if (c - k < 0 && c + k >= W) break;
+                unsigned gl[4], gq[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    gl[j] = c - k - j >= 0 ? gr[c - k - j] : G_INF;
+                    gq[j] = c + k + j < W ? gr[c + k + j] : G_INF;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const long long kk = (long long)(k + j) * (k + j);
+                    if (gl[j] != G_INF) best = min(best, (long long)gl[j] * gl[j] + kk);
+                    if (gq[j] != G_INF) best = min(best, (long long)gq[j] * gq[j] + kk);
+                }
             }
         }
         epi.store(gi, best, anybg, r0 + j, c, cnt);
