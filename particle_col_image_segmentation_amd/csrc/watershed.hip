@@ -101,6 +101,27 @@ __device__ __forceinline__ void ws_mark_neighbours(uint8_t *dirty_out, int b, in
     if (ty + 1 < tilesY) d[(ty + 1) * tilesX + tx] = 1;
 }
 
+// After a tile converged: wave e compares edge e of the tile (0 top, 1 bottom, 2 left, 3 right) with what is still in
+// global memory and marks only the neighbour that shares a CHANGED edge.  Must run BEFORE the tile is stored.
+template <typename T>
+__device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__restrict__ g, uint8_t *dirty_out, int b, int tx,
+                                                      int ty, int tilesX, int tilesY, int r0, int c0, int H, int W)
+{
+    const int e = threadIdx.x >> 6, j = threadIdx.x & 63;
+    const int lr = e == 0 ? 1 : (e == 1 ? WS_T : j + 1);
+    const int lc = e == 2 ? 1 : (e == 3 ? WS_T : j + 1);
+    const int r = r0 + lr - 1, c = c0 + lc - 1;
+    bool ch = false;
+    if (r < H && c < W) ch = s[lr * WS_P + lc] != g[(int64_t)r * W + c];
+    if (__any(ch) && j == 0) {
+        uint8_t *d = dirty_out + (int64_t)b * tilesX * tilesY;
+        if (e == 0 && ty > 0) d[(ty - 1) * tilesX + tx] = 1;
+        if (e == 1 && ty + 1 < tilesY) d[(ty + 1) * tilesX + tx] = 1;
+        if (e == 2 && tx > 0) d[ty * tilesX + tx - 1] = 1;
+        if (e == 3 && tx + 1 < tilesX) d[ty * tilesX + tx + 1] = 1;
+    }
+}
+
 // (1) minimax relaxation, tile-local fixed point in LDS
 __global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restrict__ val, unsigned *__restrict__ L,
                                                         const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
@@ -133,11 +154,10 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restric
         changed_any = true;
     }
     if (!changed_any) return;
+    ws_mark_changed_edges(sL, (const unsigned *)L + fbase, dirty_out, b, tx, ty, tilesX, tilesY, r0, c0, H, W);
+    __syncthreads();
     ws_store_tile(sL, L + fbase, r0, c0, H, W);
-    if (threadIdx.x == 0) {
-        ws_mark_neighbours(dirty_out, b, tx, ty, tilesX, tilesY);
-        *any_changed = 1;
-    }
+    if (threadIdx.x == 0) *any_changed = 1;
 }
 
 // (2) label propagation along "labelled neighbour whose key equals the minimum key of the neighbours".
@@ -436,11 +456,10 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const unsigned *__rest
         changed_any = true;
     }
     if (!changed_any) return;
+    ws_mark_changed_edges(sK, (const unsigned *)K2 + fbase, dirty_out, b, tx, ty, tilesX, tilesY, r0, c0, H, W);
+    __syncthreads();
     ws_store_tile(sK, K2 + fbase, r0, c0, H, W);
-    if (threadIdx.x == 0) {
-        ws_mark_neighbours(dirty_out, b, tx, ty, tilesX, tilesY);
-        *any_changed = 1;
-    }
+    if (threadIdx.x == 0) *any_changed = 1;
 }
 
 // K64 = (L << 32) | K2 and reset of the labels to the seeds, flagged frames only
