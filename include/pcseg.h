@@ -197,6 +197,10 @@ int pcseg_classify_regions(const int64_t *stats, const uint8_t *cls_out, const i
                            int64_t *type_stats, int32_t *region_list, int32_t *n_list, int32_t *nan_flag,
                            int B, int cap, pcseg_stream_t stream);
 
+/* ---- C14: nearest distance from every point of a (na, 2) float64 set to a (nb, 2) set = min(pdist2(a, b), [], 2)
+ * (.m:260-263 between the two ROI classes, .m:301-305 to the aggregate boundary); out_a: float64[na]. */
+int pcseg_nearest_dist_f64(const double *a, int na, const double *b, int nb, double *out_a, pcseg_stream_t stream);
+
 /* ---- C6: combine_cell_positions_and_clusters (tiff_analysis.py:252-287):
  * out = dapi with every 8-connected component of (dapi == 1) whose overlap
  * with (other == 1) exceeds `threshold` of its area set to 2. */

@@ -50,6 +50,7 @@ SIGNATURES = {
     "pcseg_merge_groups": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_group_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "pcseg_classify_regions": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "pcseg_nearest_dist_f64": (c_int, [_P, _I, _P, _I, _P, _P]),
     "pcseg_overlap_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_remove_overlapping": (c_int, [_P, _P, c_double, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_otsu_hist_f32": (c_int, [_P, _P, _P, _I, _I, _I, _P]),

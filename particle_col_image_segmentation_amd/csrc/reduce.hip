@@ -565,6 +565,22 @@ __global__ void __launch_bounds__(256) group_reduce_kernel(const long long *__re
     }
 }
 
+// ---- C14: nearest neighbour between two point sets (pdist2 + min, .m:260-263, 301-305)
+__global__ void __launch_bounds__(256) nearest_kernel(const double *__restrict__ a, int na, const double *__restrict__ b, int nb,
+                                                       double *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na) return;
+    const double ax = a[2 * i], ay = a[2 * i + 1];
+    double best = 1.0 / 0.0;
+    for (int j = 0; j < nb; ++j) {
+        double dx = ax - b[2 * j], dy = ay - b[2 * j + 1];
+        double d2 = dx * dx + dy * dy;
+        best = d2 < best ? d2 : best;
+    }
+    out[i] = sqrt(best);
+}
+
 }  // namespace pcseg
 
 using namespace pcseg;
@@ -678,6 +694,14 @@ int pcseg_group_reduce(const int64_t *stats, const int32_t *region_list, const i
                   "bad arguments");
     PCSEG_LAUNCH(group_reduce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)stats, region_list,
                        n_list, group_of, n_groups, (long long *)group_stats, cap, list_cap, H, W);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+int pcseg_nearest_dist_f64(const double *a, int na, const double *b, int nb, double *out_a, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(a && b && out_a && na >= 1 && nb >= 1, "bad arguments");
+    PCSEG_LAUNCH(nearest_kernel, dim3((na + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, out_a);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

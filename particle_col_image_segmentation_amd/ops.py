@@ -373,3 +373,17 @@ def morph3x3(mask, erode):
     out = torch.empty_like(mask)
     _lib.check(lib.pcseg_morph3x3(_ptr(mask), _ptr(out), int(bool(erode)), B, H, W, _stream()), "morph3x3")
     return out
+
+
+def nearest_dist(a, b):
+    """min over b of the Euclidean distance, for every row of a: (na,2), (nb,2) float64 CUDA tensors (.m:260-263)."""
+    a = _req(a, torch.float64, 2)
+    b = _req(b, torch.float64, 2)
+    out = torch.empty((a.shape[0],), dtype=torch.float64, device=a.device)
+    if a.shape[0] == 0:
+        return out
+    if b.shape[0] == 0:
+        return out.fill_(float("inf"))
+    lib = _lib.load()
+    _lib.check(lib.pcseg_nearest_dist_f64(_ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out), _stream()), "nearest_dist")
+    return out

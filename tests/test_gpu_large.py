@@ -1,0 +1,75 @@
+"""BASELINE's full sizes: 2048x2048 frames (configs 5) through the whole pipeline against the oracle, and a 4096x4096
+mosaic (config 4) through the kernels whose oracle still finishes in seconds, plus size-independent properties."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == bool:
+        a = a.astype(np.uint8)
+    return torch.from_numpy(a).cuda()
+
+
+def test_pipeline_2048_matches_oracle():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from particle_col_image_segmentation_amd import synth
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline
+    ct = dict(synth.CELL_TYPES_5)
+    st = synth.gen_batch_torch(4242, 1, 2048, 2048, torch.device("cuda"))
+    res = FramePipeline(ct).run(st)
+    res.check()
+    ref = orc.segment_frame(st[0].cpu().numpy(), ct)
+    np.testing.assert_array_equal(res["denoised"][0].cpu().numpy(), ref["denoised"])
+    np.testing.assert_array_equal(res["labels"][0].cpu().numpy(), ref["label_im"])
+    np.testing.assert_array_equal(res["recreated"][0].cpu().numpy(), ref["recreated"])
+    np.testing.assert_array_equal(res["ws_labels"][0].cpu().numpy(), ref["refine"]["labels"])
+    n = int(ref["label_im"].max())
+    np.testing.assert_array_equal(res["stats"][0, :n].cpu().numpy(), orc.region_table(ref["label_im"]))
+    assert int(res["particle_area"][0] + res["overlap_area"][0]) == ref["particle_area2"]
+
+
+def test_mosaic_4096_kernels():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from particle_col_image_segmentation_amd import ops, synth
+    H = W = 4096
+    st = synth.gen_batch_torch(77, 1, H, W, torch.device("cuda"))
+    cls = ops.argmax_planes(st)
+    z = ops.median5(cls)
+    zh = z[0].cpu().numpy()
+    # label: exact vs oracle
+    lab, cnt = ops.label_equal8(z)
+    exp, n = orc.label(zh, return_num=True)
+    np.testing.assert_array_equal(lab[0].cpu().numpy(), exp)
+    assert int(cnt[0]) == n
+    # region table: integer sums must add up to the frame (size-independent checksum) and match the oracle
+    stats, cls_out, _, ovf = ops.region_reduce(lab, cnt, cls=z, cap=n)
+    sth = stats[0].cpu().numpy()
+    assert int(ovf[0]) == 0 and int(sth[:, 0].sum()) == H * W
+    assert int(sth[:, 1].sum()) == (H - 1) * H // 2 * W and int(sth[:, 2].sum()) == (W - 1) * W // 2 * H
+    np.testing.assert_array_equal(sth, orc.region_table(exp, n))
+    # refine chain: EDT / maxima / markers exact vs oracle, watershed exact vs oracle
+    bm = st[:, 3]
+    d2, mask = ops.edt_sq_lt(bm, 0.5)
+    mh = mask[0].cpu().numpy().astype(bool)
+    np.testing.assert_array_equal(d2[0].cpu().numpy(), orc.edt_sq(mh))
+    is_max, markers, nm = ops.local_maxima(d2)
+    lm = orc.local_maxima(orc.edt_sq(mh))
+    np.testing.assert_array_equal(is_max[0].cpu().numpy().astype(bool), lm)
+    mk = orc.label(lm)
+    np.testing.assert_array_equal(markers[0].cpu().numpy(), mk)
+    ws, flags = ops.watershed(bm, markers, mask)
+    wsh = ws[0].cpu().numpy()
+    np.testing.assert_array_equal(wsh, orc.watershed(bm[0].cpu().numpy(), mk, mh))
+    # properties: labels only inside the mask, every marker id survives, idempotent relabelling
+    assert (wsh[~mh] == 0).all() and set(np.unique(wsh)) - {0} == set(range(1, int(nm[0]) + 1))
+    # dilation identity at full size: dilate(m, disk(2)) == EDT^2(~m) <= 4
+    dil = ops.dilate_disk(z, 1 << 1, 2)[0].cpu().numpy().astype(bool)
+    np.testing.assert_array_equal(dil, orc.edt_sq(zh != 1) <= 4)
