@@ -527,3 +527,79 @@ def process_single_h5_file(cur_folder, file_path):
     merged_file_name = cell_pos_file_name.replace("_cell_pos.csv", "_merged_cell_pos.csv")
     write_merged_cell_position_info(merged_clusters, merged_file_name, particle_area)
     write_density_info(density_info_file_path, processed_folder, cell_density, cell_area_ratio, cell_count)
+
+
+def process_multiple_h5_files(cur_folder, h5_files):
+    """tiff_analysis.py:92-222 without the matplotlib figures: per-channel class maps of one sample (DAPI / RFP / GFP),
+    DAPI cells that overlap the other channel removed (:167), channels recombined (:202-204), merged clusters of the
+    combined map (:206); writes *_cell_pos_raw.csv, *_cell_pos_combined.csv, *_merged_cell_pos.csv and the density CSV."""
+    density_info_file_path, cell_pos_file_name = get_pos_and_density_file_names(cur_folder)
+    cell_pos_raw_file_name = cell_pos_file_name.replace("_cell_pos.csv", "_cell_pos_raw.csv")
+    cell_pos_combined_file_name = cell_pos_file_name.replace("_cell_pos.csv", "_cell_pos_combined.csv")
+    processed_folder = cur_folder.split("/")[-1]
+    rfp_particle_area = None
+    master_cell_pos = {}
+    master_cell_clusters = {}
+    channel_ds_arrs = {}
+    dapi_cell_types = None
+    cell_strains = get_strains_from_file(cur_folder)
+    for file in h5_files:
+        full_file_path = os.path.join(cur_folder, file)
+        channel = get_channel_from_file(file)
+        cell_types = get_cell_type_map_from_channel(cell_strains, channel)
+        strain_type = cell_types[1]
+        if len(cell_types) == 0:
+            raise ValueError("Cell type not found in file path")
+        ds_arr = normalize_ds_arr(read_class_map(full_file_path))
+        ds_arr_denoised = median_filter(ds_arr, size=DENOISE_SIZE)
+        cell_positions, cell_clusters, particle_area, _ = get_cell_positions_and_areas(ds_arr_denoised, cell_types)
+        channel_ds_arrs[channel] = ds_arr_denoised
+        if channel == "RFP":
+            rfp_particle_area = particle_area
+            _, rfp_particle_area = recreate_particle_area(ds_arr_denoised, cell_types, particle_area)
+            if strain_type == "Particle":
+                continue
+        elif channel == "DAPI":
+            dapi_cell_types = cell_types
+        if strain_type not in CELL_TYPES:
+            raise ValueError(f"Strain type not in cell types. {strain_type}")
+        master_cell_pos.update(cell_positions)
+        master_cell_clusters.update(cell_clusters)
+    if rfp_particle_area is None:
+        raise ValueError("RFP particle area not found")
+    write_cell_position_info(master_cell_pos, master_cell_clusters, cell_pos_raw_file_name, rfp_particle_area)
+    if len(cell_strains) > 1:
+        other_channel = channel_ds_arrs["GFP"] if cell_strains == ["6B07", "C3M10"] else channel_ds_arrs["RFP"]
+        dapi_updated = combine_cell_positions_and_clusters(channel_ds_arrs["DAPI"], other_channel)
+        dapi_cell_positions, dapi_cell_clusters, _, _ = get_cell_positions_and_areas(dapi_updated, dapi_cell_types)
+        master_cell_pos["6B07"] = dapi_cell_positions["6B07"]
+        master_cell_clusters["6B07"] = dapi_cell_clusters["6B07"]
+    cell_counts, cell_densities, cell_area_ratios = get_cell_counts_and_densities(
+        master_cell_pos, master_cell_clusters, rfp_particle_area)
+    write_density_info(density_info_file_path, processed_folder, cell_densities, cell_area_ratios, cell_counts)
+    rfp_base_arr = channel_ds_arrs["RFP"].copy()
+    get_rfp_base_arr(rfp_base_arr, cell_strains)
+    combined_channels = combine_channels(rfp_base_arr, channel_ds_arrs, cell_strains)
+    _, _, _, merged_clusters = get_cell_positions_and_areas(combined_channels, BASE_TYPE_MAP, merged=True)
+    write_cell_position_info(master_cell_pos, master_cell_clusters, cell_pos_combined_file_name, rfp_particle_area)
+    merged_file_name = cell_pos_combined_file_name.replace("_cell_pos_combined.csv", "_merged_cell_pos.csv")
+    write_merged_cell_position_info(merged_clusters, merged_file_name, rfp_particle_area)
+    return combined_channels, merged_clusters
+
+
+def process_h5_folder(cur_folder, h5_files):
+    """tiff_analysis.py:85-89."""
+    if len(h5_files) == 1:
+        process_single_h5_file(cur_folder, h5_files[0])
+    else:
+        process_multiple_h5_files(cur_folder, h5_files)
+
+
+def get_h5_files_recursively(folder_path, suffixes=(".h5", ".npy")):
+    """tiff_analysis.py:1113-1123 (also picks up .npy class maps)."""
+    h5_files = {}
+    for root, _, files in os.walk(folder_path):
+        for file in files:
+            if file.endswith(tuple(suffixes)):
+                h5_files.setdefault(root, []).append(file)
+    return h5_files

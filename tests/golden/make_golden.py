@@ -375,6 +375,53 @@ def e2e_case():
     save("e2e_single", **out)
 
 
+def e2e_multi_case():
+    """process_h5_folder on a two-file folder -> process_multiple_h5_files (tiff_analysis.py:92-222): DAPI (6B07) + RFP
+    (3D05) channels, overlap removal, channel recombination, merged clusters.  The matplotlib figure builders are
+    stubbed out at run time (they only write PNGs); every CSV comes from the reference's own code."""
+    import h5py
+    for fn in ("create_channel_plots", "visualize_dapi_overlap_results", "plot_original_vs_merged", "create_plot"):
+        setattr(ta, fn, lambda *a, **k: None)
+    H = W = 128
+    rng = np.random.default_rng(99)
+    for seed in range(400, 480):
+        stack = synth.gen_frame(seed, H, W)
+        cm = synth.class_map_from_stack(stack)
+        rfp = np.where(cm == 1, 1, np.where(cm == 3, 2, 3)).astype(np.uint8)
+        extra = (cm == 1) & (ndi.label(cm == 1)[0] % 3 == 0)      # a third of the 3D05 cells also light up in DAPI
+        dapi = np.where((cm == 2) | extra, 1, np.where(cm == 3, 2, 3)).astype(np.uint8)
+        tmp = tempfile.mkdtemp()
+        folder = os.path.join(tmp, "3D05_6B07", "24h", "Tp_3D05_6B07_1_24h_60X_1")
+        os.makedirs(folder)
+        files = ["Tp_3D05_6B07_1_24h_60X_1_DAPI_Simple Segmentation.h5", "Tp_3D05_6B07_1_24h_60X_1_RFP_Simple Segmentation.h5"]
+        for fn, arr in zip(files, (dapi, rfp)):
+            with h5py.File(os.path.join(folder, fn), "w") as f:
+                f["exported_data"] = arr[None, :, :]
+        so = sys.stdout
+        sys.stdout = io.StringIO()
+        try:
+            ta.process_h5_folder(folder, files)
+            ok = True
+        except ValueError:
+            ok = False
+        finally:
+            sys.stdout = so
+        if not ok:
+            shutil.rmtree(tmp)
+            continue
+        out = {"dapi": dapi, "rfp": rfp, "files": np.array(files), "seed": np.int64(seed)}
+        for root, _, fs in os.walk(tmp):
+            for fn in sorted(fs):
+                if fn.endswith(".csv"):
+                    rel = os.path.relpath(os.path.join(root, fn), tmp)
+                    with open(os.path.join(root, fn), "rb") as f:
+                        out["csv:" + rel] = np.frombuffer(f.read(), np.uint8)
+        shutil.rmtree(tmp)
+        save("e2e_multi", **out)
+        return
+    raise RuntimeError("no seed worked")
+
+
 def split_case():
     """split_zstack.process_tif / process_folder (split_zstack.py:38-89)."""
     import tifffile
@@ -437,6 +484,7 @@ def main():
     overlap_case()
     e2e_case()
     split_case()
+    e2e_multi_case()
 
 
 if __name__ == "__main__":

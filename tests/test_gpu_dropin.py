@@ -136,3 +136,32 @@ def test_e2e_single_folder(ta, tmp_path):
         rel = k[4:]
         got = open(os.path.join(str(tmp_path), rel), "rb").read()
         assert got == g[k].tobytes(), rel
+
+
+def test_e2e_multi_channel_folder(ta, tmp_path):
+    """process_multiple_h5_files (DAPI + RFP channels of one sample): every CSV the reference wrote, byte for byte
+    (the merged CSV per type, because the reference orders its types by a hash-randomised set)."""
+    g = load_golden("e2e_multi")
+    folder = tmp_path / "3D05_6B07" / "24h" / "Tp_3D05_6B07_1_24h_60X_1"
+    folder.mkdir(parents=True)
+    files = []
+    for fn, key in zip(g["files"], ("dapi", "rfp")):
+        name = str(fn).replace(".h5", ".npy")
+        np.save(str(folder / name), g[key][None, :, :])
+        files.append(name)
+    ta.process_h5_folder(str(folder), files)
+    n = 0
+    for k in g.files:
+        if not k.startswith("csv:"):
+            continue
+        got = open(os.path.join(str(tmp_path), k[4:]), "rb").read()
+        exp = g[k].tobytes()
+        if k.endswith("_merged_cell_pos.csv"):
+            assert sorted(got.split(b"\r\n")) == sorted(exp.split(b"\r\n")), k
+            for t in (b"3D05", b"6B07"):
+                pick = lambda txt: [r for r in txt.split(b"\r\n") if r.startswith(t)]
+                assert pick(got) == pick(exp)
+        else:
+            assert got == exp, k
+        n += 1
+    assert n == 4
