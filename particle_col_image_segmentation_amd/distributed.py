@@ -44,10 +44,31 @@ def all_gather_table(table, group=None, sort_cols=(0, 1)):
 def gather_tables(tables, device=None, group=None):
     """all-gather every table of FramePipeline.tables() (numpy in, numpy out)."""
     out = dict(tables)
-    for name in ("cells", "rois", "frames", "groups"):
-        t = torch.from_numpy(np.ascontiguousarray(tables[name]))
+    for name in [k for k, v in tables.items() if isinstance(v, np.ndarray) and v.ndim == 2]:
+        t = torch.from_numpy(np.ascontiguousarray(tables[name], dtype=np.float64))
         if device is not None:
             t = t.to(device)
         sort_cols = (0,) if name == "frames" else ((0, 1, 2) if name == "groups" else (0, 1))
         out[name] = all_gather_table(t, group, sort_cols).cpu().numpy()
     return out
+
+
+def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None):
+    """BASELINE configs 3 / 5: frames ``rank, rank + world, ...`` of a dataset go through ``pipe`` in batches of
+    ``batch`` and the per-ROI tables of all ranks are gathered once at the end.  ``make_batch(frame_ids)`` returns the
+    ``(len(frame_ids), C, H, W)`` float32 CUDA stack of those frames (e.g. ``synth.gen_batch_torch`` per seed, or
+    frames written by ``split_zstack.process_tif``)."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    mine = shard_frames(n_frames, rank, world)
+    parts = []
+    for i in range(0, len(mine), batch):
+        ids = mine[i:i + batch]
+        res = pipe.run(make_batch(ids))
+        parts.append(pipe.tables(res, frame_ids=ids))
+    if parts:
+        merged = {k: (np.concatenate([p[k] for p in parts]) if isinstance(parts[0][k], np.ndarray) else parts[0][k])
+                  for k in parts[0]}
+    else:
+        merged = {"cells": np.zeros((0, 1)), "rois": np.zeros((0, 1)), "frames": np.zeros((0, 1)), "groups": np.zeros((0, 11))}
+    return gather_tables(merged, device=device, group=group)

@@ -387,3 +387,29 @@ def nearest_dist(a, b):
     lib = _lib.load()
     _lib.check(lib.pcseg_nearest_dist_f64(_ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out), _stream()), "nearest_dist")
     return out
+
+
+def threshold_otsu(img):
+    """Otsu threshold per frame from the device histogram (north_star extension X1, no reference call site): bin
+    centres over [min, max], between-class variance maximised over the split index (host epilogue on 256 numbers)."""
+    import numpy as np
+    hist, lohi = otsu_hist(img)
+    h = hist.cpu().numpy().astype(np.float64)
+    lh = lohi.cpu().numpy().astype(np.float64)
+    out = np.empty(h.shape[0], np.float64)
+    for b in range(h.shape[0]):
+        lo, hi = lh[b]
+        if hi == lo:
+            out[b] = lo
+            continue
+        edges = lo + (hi - lo) * (np.arange(257) / 256.0)
+        centers = (edges[:-1] + edges[1:]) / 2.0
+        w1 = np.cumsum(h[b])[:-1]
+        s1 = np.cumsum(h[b] * centers)[:-1]
+        wt, stt = h[b].sum(), (h[b] * centers).sum()
+        w2 = wt - w1
+        with np.errstate(all="ignore"):
+            var = w1 * w2 * (s1 / w1 - (stt - s1) / w2) ** 2
+        var[(w1 == 0) | (w2 == 0)] = -1.0
+        out[b] = centers[int(np.argmax(var))]
+    return out

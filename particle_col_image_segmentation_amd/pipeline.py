@@ -111,7 +111,7 @@ class FramePipeline:
         return res
 
     # ------------------------------------------------------------------ host epilogue
-    def tables(self, res, frame_ids=None, ratios=RATIOS_5):
+    def tables(self, res, frame_ids=None, ratios=RATIOS_5, distances=False, raster=19.0):
         """Download one batch as numpy tables: ``cells`` (one row per cell / cluster region), ``rois`` (one row per
         refined ROI), ``frames`` (one row per frame) and ``groups`` (one row per merged group)."""
         res.check()
@@ -129,7 +129,7 @@ class FramePipeline:
                 group_of[s] = (g["group_of"].cpu().numpy(), g["n_groups"].cpu().numpy(), g["group_stats"].cpu().numpy(),
                                res["region_list"][:, s].cpu().numpy(), res["n_list"][:, s].cpu().numpy())
         nr = len(ratios)
-        cell_rows, roi_rows, frame_rows, group_rows = [], [], [], []
+        cell_rows, roi_rows, frame_rows, group_rows, dist_rows = [], [], [], [], []
         for b in range(B):
             n = int(counts[b])
             st, sums = stats[b, :n], cc_sums[b, :n]
@@ -167,6 +167,19 @@ class FramePipeline:
                     dens = round(count / pa_um, 5) if present and pa_um else float("nan")
                     ratio = round(area / pa_um, 5) if present and pa_um else float("nan")
                 row += [int(present), count, dens, ratio]
+            if distances:
+                # .m:260-268 per frame: nearest ROI of the other cell type for the cells / clusters of slots 0 and 1
+                a = [[st[r, 2] / st[r, 0] + 1.0, st[r, 1] / st[r, 0] + 1.0] for r in sel if slot_of[b, r] == 0]
+                c = [[st[r, 2] / st[r, 0] + 1.0, st[r, 1] / st[r, 0] + 1.0] for r in sel if slot_of[b, r] == 1]
+                if a and c:
+                    dev = res["stats"].device
+                    ta_ = torch.tensor(a, dtype=torch.float64, device=dev)
+                    tc_ = torch.tensor(c, dtype=torch.float64, device=dev)
+                    da, dc = ops.nearest_dist(ta_, tc_).cpu().numpy(), ops.nearest_dist(tc_, ta_).cpu().numpy()
+                    ia = [r for r in sel if slot_of[b, r] == 0]
+                    ic = [r for r in sel if slot_of[b, r] == 1]
+                    for r, d in list(zip(ia, da)) + list(zip(ic, dc)):
+                        dist_rows.append([frame_ids[b], r + 1, d / (512.0 / raster)])
             frame_rows.append(row)
         ncols_cell = 14 + C + nr
         ncols_roi = 5 + C + nr
@@ -181,6 +194,8 @@ class FramePipeline:
             "frames": np.array(frame_rows, np.float64).reshape(B, -1),
             "frames_columns": ["frame", "n_labels", "n_rois", "particle_area", "particle_area_recreated", "tie_flag"]
                               + [c % n for n in tb.slot_names for c in ("%s_present", "%s_count", "%s_density", "%s_area_ratio")],
+            "distances": np.array(dist_rows, np.float64).reshape(-1, 3),
+            "distances_columns": ["frame", "label", "nearest_other_type_um"],
             "groups": np.array(group_rows, np.float64).reshape(-1, 11),
             "groups_columns": ["frame", "slot", "group", "area", "centroid_row", "centroid_col", "min_row", "min_col",
                                "max_row1", "max_col1", "members"],

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from particle_col_image_segmentation_amd.distributed import all_gather_table, gather_tables, shard_frames
+from particle_col_image_segmentation_amd.distributed import all_gather_table, gather_tables, run_sharded, shard_frames
 
 
 def _fake_tables(frames):
@@ -67,3 +67,34 @@ def test_two_and_three_rank_gather_equals_single(tmp_path):
         g = np.load(str(tmp_path / ("g%d.npz" % world)))
         for name in ("cells", "rois", "frames"):
             np.testing.assert_array_equal(g[name], single[name])
+
+
+class _FakePipe:
+    """Stands in for FramePipeline on CPU: run() just remembers the frame ids carried in the 'stack'."""
+
+    def run(self, stack):
+        return stack
+
+    def tables(self, res, frame_ids=None):
+        assert list(res) == list(frame_ids)
+        return _fake_tables(frame_ids)
+
+
+def _worker_sharded(rank, world, port, n_frames, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gathered = run_sharded(n_frames, lambda ids: ids, _FakePipe(), batch=3)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "s%d.npz" % world), **{k: v for k, v in gathered.items() if isinstance(v, np.ndarray)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_sharded_two_ranks_equals_single(tmp_path):
+    n_frames = 10
+    single = _fake_tables(range(n_frames))
+    mp.spawn(_worker_sharded, args=(2, _free_port(), n_frames, str(tmp_path)), nprocs=2, join=True)
+    g = np.load(str(tmp_path / "s2.npz"))
+    for name in ("cells", "rois", "frames"):
+        np.testing.assert_array_equal(g[name], single[name])

@@ -310,3 +310,6 @@ def test_extensions_otsu_morph(ops):
         thr, h = orc.threshold_otsu(img[i])
         np.testing.assert_array_equal(host(hist)[i], h)
         assert float(lohi[i, 0]) == img[i].min() and float(lohi[i, 1]) == img[i].max()
+    thr = ops.threshold_otsu(dev(img))
+    for i in range(2):
+        assert abs(thr[i] - orc.threshold_otsu(img[i])[0]) < 1e-12
