@@ -126,6 +126,13 @@ int pcseg_edt_sq_lt_f32(const float *img, int64_t frame_stride, float threshold,
 int pcseg_dilate_disk_u8(const uint8_t *in, uint64_t value_bits, int radius, uint8_t *out,
                          int B, int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
 
+/* ---- A6 fused: components of binary_dilation(((value_bits >> in) & 1), disk(radius)) as a union-find parent
+ * image (int32 (B,H,W): linear index of a pixel of the same component, -1 = background), computed on a 1-bit image
+ * (the dilation is shifts / ORs of 32-row column words).  Feeds pcseg_merge_groups(keys_are_roots = 1). */
+size_t pcseg_dilate_ccl_workspace_bytes(int B, int H, int W);
+int pcseg_dilate_ccl_roots_u8(const uint8_t *in, uint64_t value_bits, int radius, int32_t *roots,
+                              int B, int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
 /* ---- A8: fill_particle_area (tiff_analysis.py:982-1015) in one pass pair:
  * out = ds with overlap pixels set to overlap_label, where overlap =
  * (ds == cell_label) & (EDT(ds != particle) < dist_threshold | dilate(ds ==
@@ -152,7 +159,9 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
  * [sync]  mode 0: parallel flood + proof check, frames that fail the check
  * are re-run by the exact sequential priority flood; mode 1: exact sequential
  * flood for every frame; mode 2: parallel flood only (tie_flags tells which
- * frames are NOT proven exact).  tie_flags: device int32[B] (may be NULL).
+ * frames are NOT proven exact); add 4 to also run the explicit per-pixel proof
+ * check (implied by the component test, kept for verification).  tie_flags:
+ * device int32[B] (may be NULL).
  * frame_stride: as for pcseg_edt_sq_lt_f32 (0 = H*W). */
 size_t pcseg_watershed_workspace_bytes(int B, int H, int W);
 int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *markers, const uint8_t *mask,
@@ -165,10 +174,12 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
  * dilated_labels at the truncated centroid; list entries sharing a non-zero
  * key form one group, groups numbered 1.. in the order of their first member;
  * group_of[b][k] = group id or 0 (centroid on a zero pixel -> dropped, :848).
- * region_list / group_of: int32 (B, list_cap); n_list / n_groups: int32[B]. */
+ * region_list / group_of: int32 (B, list_cap); n_list / n_groups: int32[B].
+ * keys_are_roots != 0: `dilated_labels` is the parent image of pcseg_dilate_ccl_roots_u8 (no numbering pass needed,
+ * groups only need "same component"). */
 size_t pcseg_merge_groups_workspace_bytes(int B, int list_cap);
-int pcseg_merge_groups(const int32_t *dilated_labels, const int64_t *stats, const int32_t *region_list,
-                       const int32_t *n_list, int32_t *group_of, int32_t *n_groups,
+int pcseg_merge_groups(const int32_t *dilated_labels, int keys_are_roots, const int64_t *stats,
+                       const int32_t *region_list, const int32_t *n_list, int32_t *group_of, int32_t *n_groups,
                        int B, int H, int W, int cap, int list_cap, void *workspace, size_t workspace_bytes,
                        pcseg_stream_t stream);
 

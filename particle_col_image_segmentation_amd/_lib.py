@@ -47,7 +47,9 @@ SIGNATURES = {
     "pcseg_watershed_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_watershed4_f32": (c_int, [_P, c_int64, _P, _P, _P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_merge_groups_workspace_bytes": (c_size_t, [_I, _I]),
-    "pcseg_merge_groups": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, c_size_t, _P]),
+    "pcseg_merge_groups": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, c_size_t, _P]),
+    "pcseg_dilate_ccl_workspace_bytes": (c_size_t, [_I, _I, _I]),
+    "pcseg_dilate_ccl_roots_u8": (c_int, [_P, c_uint64, _I, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_group_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "pcseg_classify_regions": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "pcseg_nearest_dist_f64": (c_int, [_P, _I, _P, _I, _P, _P]),

@@ -16,26 +16,44 @@ namespace pcseg {
 constexpr int CCL_TW = 64, CCL_TH = 32, CCL_TILE = CCL_TW * CCL_TH;
 constexpr int SCAN_PIX = 1024;  // pixels per block in the count / assign / relabel passes
 
-// ---- key functors: 0 = background, equal non-zero keys connect
+// ---- key functors: key(b, r, c) of pixel (r, c) of frame b; 0 = background, equal non-zero keys connect
 struct KeyEqU8 {
     const uint8_t *p;
-    __device__ __forceinline__ int operator()(int64_t i) const { return p[i]; }
+    int W;
+    int64_t n;
+    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + (int64_t)r * W + c]; }
 };
 struct KeyNzU8 {
     const uint8_t *p;
-    __device__ __forceinline__ int operator()(int64_t i) const { return p[i] != 0; }
+    int W;
+    int64_t n;
+    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + (int64_t)r * W + c] != 0; }
 };
 struct KeyZeroU8 {  // background components (fill holes)
     const uint8_t *p;
-    __device__ __forceinline__ int operator()(int64_t i) const { return p[i] == 0; }
+    int W;
+    int64_t n;
+    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + (int64_t)r * W + c] == 0; }
 };
 struct KeyIsOneU8 {  // dapi == 1
     const uint8_t *p;
-    __device__ __forceinline__ int operator()(int64_t i) const { return p[i] == 1; }
+    int W;
+    int64_t n;
+    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + (int64_t)r * W + c] == 1; }
 };
 struct KeyI32 {
     const int32_t *p;
-    __device__ __forceinline__ int operator()(int64_t i) const { return p[i]; }
+    int W;
+    int64_t n;
+    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + (int64_t)r * W + c]; }
+};
+struct KeyBits {  // 1 bit per pixel in 32-row column words: words[(b * nch + r / 32) * W + c] bit (r % 32)
+    const unsigned *words;
+    int W, nch;
+    __device__ __forceinline__ int operator()(int b, int r, int c) const
+    {
+        return (words[((int64_t)b * nch + (r >> 5)) * W + c] >> (r & 31)) & 1u;
+    }
 };
 
 template <typename KeyFn, bool CONN8>
@@ -47,7 +65,7 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(KeyFn keyfn, int *__restr
     const int64_t fbase = (int64_t)b * H * W;
     for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
         int r = r0 + i / CCL_TW, c = c0 + i % CCL_TW;
-        key[i] = (r < H && c < W) ? keyfn(fbase + (int64_t)r * W + c) : 0;
+        key[i] = (r < H && c < W) ? keyfn(b, r, c) : 0;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
@@ -91,16 +109,17 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(KeyFn keyfn, int *__res
     const bool left = (c % CCL_TW) == 0 && c > 0;
     const bool right = (c % CCL_TW) == CCL_TW - 1 && c + 1 < W;
     if (!top && !left && !(CONN8 && right && r > 0)) return;
-    const int64_t fbase = (int64_t)blockIdx.z * H * W;
+    const int b = blockIdx.z;
+    const int64_t fbase = (int64_t)b * H * W;
     int *par = parent + fbase;
     const int p = r * W + c;
-    const int k = keyfn(fbase + p);
+    const int k = keyfn(b, r, c);
     if (k == 0) return;
     // the same "implied link" rule as inside a tile: a link is skipped when the two pixels are already joined through
     // a third one whose links are made elsewhere (run links inside a tile row, vertical links of the left neighbour)
-    const bool w_same = c > 0 && keyfn(fbase + p - 1) == k;
-    const bool n_same = r > 0 && keyfn(fbase + p - W) == k;
-    const bool nw_same = r > 0 && c > 0 && keyfn(fbase + p - W - 1) == k;
+    const bool w_same = c > 0 && keyfn(b, r, c - 1) == k;
+    const bool n_same = r > 0 && keyfn(b, r - 1, c) == k;
+    const bool nw_same = r > 0 && c > 0 && keyfn(b, r - 1, c - 1) == k;
     // (at a tile corner both the W and the N link cross tiles and would justify each other: keep both there)
     const bool corner = top && left;
     if (left && w_same && (corner || !(n_same && nw_same))) unite_glb(par, p, p - 1);
@@ -108,7 +127,7 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(KeyFn keyfn, int *__res
         if (top && n_same && (corner || !(w_same && nw_same))) unite_glb(par, p, p - W);
         if (CONN8) {
             if ((top || left) && nw_same && !n_same && !w_same) unite_glb(par, p, p - W - 1);
-            if (c + 1 < W && (top || right) && !n_same && keyfn(fbase + p - W + 1) == k) unite_glb(par, p, p - W + 1);
+            if (c + 1 < W && (top || right) && !n_same && keyfn(b, r - 1, c + 1) == k) unite_glb(par, p, p - W + 1);
         }
     }
 }
@@ -302,6 +321,61 @@ __global__ void __launch_bounds__(256) roots_to_parent_kernel(const int *__restr
     if (i < total) parent[i] = roots[i] - 1;
 }
 
+// ---- disk(r) dilation on the 1-bit image + components of the result, roots only (A6) -------------------------
+// set bits: 1 where ((value_bits >> in) & 1), rows beyond H are 0
+__global__ void __launch_bounds__(256) set_bits_kernel(const uint8_t *__restrict__ in, unsigned long long value_bits,
+                                                        unsigned *__restrict__ bits, int H, int W, int nch)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    if (c >= W) return;
+    const uint8_t *src = in + (int64_t)b * H * W;
+    unsigned word = 0;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+        int r = ch * 32 + j;
+        if (r < H) {
+            unsigned v = src[(int64_t)r * W + c];
+            if (v < 64 && ((value_bits >> v) & 1ull)) word |= 1u << j;
+        }
+    }
+    bits[((int64_t)b * nch + ch) * W + c] = word;
+}
+
+// out = dilate(in, disk(radius)): for every row offset dy the columns within half(dy) = floor(sqrt(r^2 - dy^2)) are
+// OR-ed, then shifted by dy rows across the 32-row words (skimage disk: x^2 + y^2 <= r^2; outside the image = 0)
+__global__ void __launch_bounds__(256) dilate_bits_kernel(const unsigned *__restrict__ in, unsigned *__restrict__ out,
+                                                           int radius, int H, int W, int nch)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    if (c >= W) return;
+    const unsigned *base = in + (int64_t)b * nch * W;
+    unsigned acc = 0;
+    for (int dy = 0; dy <= radius; ++dy) {
+        int half = 0;
+        while ((half + 1) * (half + 1) + dy * dy <= radius * radius) ++half;
+        unsigned cur = 0, prev = 0, next = 0;  // OR over the columns c-half..c+half of this word / the word above / below
+        for (int dx = -half; dx <= half; ++dx) {
+            int cc = c + dx;
+            if (cc < 0 || cc >= W) continue;
+            cur |= base[(int64_t)ch * W + cc];
+            if (dy > 0) {
+                if (ch > 0) prev |= base[(int64_t)(ch - 1) * W + cc];
+                if (ch + 1 < nch) next |= base[(int64_t)(ch + 1) * W + cc];
+            }
+        }
+        if (dy == 0) acc |= cur;
+        else {
+            acc |= (cur << dy) | (prev >> (32 - dy));  // source rows above move down by dy
+            acc |= (cur >> dy) | (next << (32 - dy));  // source rows below move up by dy
+        }
+    }
+    const int rows = min(32, H - ch * 32);
+    if (rows < 32) acc &= (1u << rows) - 1u;
+    out[((int64_t)b * nch + ch) * W + c] = acc;
+}
+
 // ---- fill holes ------------------------------------------------------------
 __global__ void __launch_bounds__(256) border_flag_kernel(const int *__restrict__ parent, uint8_t *__restrict__ flag, int H, int W)
 {
@@ -452,21 +526,49 @@ int pcseg_ccl8_equal_u8(const uint8_t *in, int32_t *labels, int32_t *counts, int
                         size_t workspace_bytes, pcseg_stream_t stream)
 {
     PCSEG_REQUIRE(in && labels && counts && workspace && check_shape(B, H, W), "bad arguments");
-    return ccl_full<KeyEqU8, true>(KeyEqU8{in}, labels, counts, B, H, W, workspace, workspace_bytes, (hipStream_t)stream);
+    return ccl_full<KeyEqU8, true>(KeyEqU8{in, W, (int64_t)H * W}, labels, counts, B, H, W, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int pcseg_ccl8_bool(const uint8_t *in, int32_t *labels, int32_t *counts, int B, int H, int W, void *workspace,
                     size_t workspace_bytes, pcseg_stream_t stream)
 {
     PCSEG_REQUIRE(in && labels && counts && workspace && check_shape(B, H, W), "bad arguments");
-    return ccl_full<KeyNzU8, true>(KeyNzU8{in}, labels, counts, B, H, W, workspace, workspace_bytes, (hipStream_t)stream);
+    return ccl_full<KeyNzU8, true>(KeyNzU8{in, W, (int64_t)H * W}, labels, counts, B, H, W, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int pcseg_ccl4_bool(const uint8_t *in, int32_t *labels, int32_t *counts, int B, int H, int W, void *workspace,
                     size_t workspace_bytes, pcseg_stream_t stream)
 {
     PCSEG_REQUIRE(in && labels && counts && workspace && check_shape(B, H, W), "bad arguments");
-    return ccl_full<KeyNzU8, false>(KeyNzU8{in}, labels, counts, B, H, W, workspace, workspace_bytes, (hipStream_t)stream);
+    return ccl_full<KeyNzU8, false>(KeyNzU8{in, W, (int64_t)H * W}, labels, counts, B, H, W, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t pcseg_dilate_ccl_workspace_bytes(int B, int H, int W)
+{
+    if (!check_shape(B, H, W)) return 0;
+    int nch = (H + 31) / 32;
+    return 2 * align_up(sizeof(unsigned) * (size_t)B * nch * W);
+}
+
+int pcseg_dilate_ccl_roots_u8(const uint8_t *in, uint64_t value_bits, int radius, int32_t *roots, int B, int H, int W,
+                              void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(in && roots && workspace && radius >= 0 && radius <= 15 && check_shape(B, H, W), "bad arguments (radius <= 15)");
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = (H + 31) / 32;
+    Carver cv(workspace, workspace_bytes);
+    unsigned *bits = cv.take<unsigned>((size_t)B * nch * W);
+    unsigned *dil = cv.take<unsigned>((size_t)B * nch * W);
+    if (!cv.ok()) {
+        set_error("dilate_ccl_roots: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    dim3 g((W + 255) / 256, nch, B);
+    PCSEG_LAUNCH(set_bits_kernel, g, dim3(256), 0, s, in, (unsigned long long)value_bits, bits, H, W, nch);
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, dil, radius, H, W, nch);
+    PCSEG_CHECK_LAUNCH();
+    return ccl_roots<KeyBits, true>(KeyBits{dil, W, nch}, roots, B, H, W, s);
 }
 
 int pcseg_compact_labels(const int32_t *roots, int32_t *labels, int32_t *counts, int B, int H, int W, void *workspace,
@@ -505,7 +607,7 @@ int pcseg_fill_holes(const uint8_t *mask, uint8_t *out, int B, int H, int W, voi
         set_error("fill_holes: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
     }
-    int rc = ccl_roots<KeyZeroU8, false>(KeyZeroU8{mask}, ws.parent, B, H, W, s);
+    int rc = ccl_roots<KeyZeroU8, false>(KeyZeroU8{mask, W, (int64_t)H * W}, ws.parent, B, H, W, s);
     if (rc) return rc;
     dim3 g1((unsigned)((n + 255) / 256), B);
     PCSEG_LAUNCH(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);
@@ -546,7 +648,7 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
     dim3 g2((W + 63) / 64, (H + 3) / 4, B);
     PCSEG_LAUNCH(locmax_candidates_kernel, g2, dim3(256), 0, s, img, key, nonconst, H, W);
     PCSEG_CHECK_LAUNCH();
-    int rc = ccl_roots<KeyI32, true>(KeyI32{key}, ws.parent, B, H, W, s);
+    int rc = ccl_roots<KeyI32, true>(KeyI32{key, W, (int64_t)H * W}, ws.parent, B, H, W, s);
     if (rc) return rc;
     dim3 g1((unsigned)((n + 255) / 256), B);
     PCSEG_LAUNCH(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);
@@ -587,7 +689,7 @@ int pcseg_remove_overlapping(const uint8_t *dapi, const uint8_t *other, double t
         set_error("remove_overlapping: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
     }
-    int rc = ccl_roots<KeyIsOneU8, true>(KeyIsOneU8{dapi}, ws.parent, B, H, W, s);
+    int rc = ccl_roots<KeyIsOneU8, true>(KeyIsOneU8{dapi, W, (int64_t)H * W}, ws.parent, B, H, W, s);
     if (rc) return rc;
     dim3 g1((unsigned)((n + 255) / 256), B);
     PCSEG_LAUNCH(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);

@@ -160,8 +160,8 @@ struct RegionSlots {
 
 template <int NC>
 __device__ __forceinline__ void region_commit(const RegionSlots &ls, long long *gst, double *gsum, int *overflow, int b, int cap,
-                                              int C, int l, long long s_area, long long s_r, long long s_c, long long r,
-                                              long long c0, long long c1, long long first, const double *acc)
+                                              int C, int l, long long s_area, long long s_r, long long s_c, long long rmin,
+                                              long long rmax1, long long c0, long long c1, long long first, const double *acc)
 {
     if (l > cap) {
         if (overflow) overflow[b] = 1;
@@ -173,9 +173,9 @@ __device__ __forceinline__ void region_commit(const RegionSlots &ls, long long *
         atomicAdd((unsigned long long *)&ls.lstat[slot][0], (unsigned long long)s_area);
         atomicAdd((unsigned long long *)&ls.lstat[slot][1], (unsigned long long)s_r);
         atomicAdd((unsigned long long *)&ls.lstat[slot][2], (unsigned long long)s_c);
-        atomic_min_i64(&ls.lstat[slot][3], r);
+        atomic_min_i64(&ls.lstat[slot][3], rmin);
         atomic_min_i64(&ls.lstat[slot][4], c0);
-        atomic_max_i64(&ls.lstat[slot][5], r + 1);
+        atomic_max_i64(&ls.lstat[slot][5], rmax1);
         atomic_max_i64(&ls.lstat[slot][6], c1 + 1);
         atomic_min_i64(&ls.lstat[slot][7], first);
 #pragma unroll
@@ -186,9 +186,9 @@ __device__ __forceinline__ void region_commit(const RegionSlots &ls, long long *
         atomicAdd((unsigned long long *)&t[0], (unsigned long long)s_area);
         atomicAdd((unsigned long long *)&t[1], (unsigned long long)s_r);
         atomicAdd((unsigned long long *)&t[2], (unsigned long long)s_c);
-        atomic_min_i64(&t[3], r);
+        atomic_min_i64(&t[3], rmin);
         atomic_min_i64(&t[4], c0);
-        atomic_max_i64(&t[5], r + 1);
+        atomic_max_i64(&t[5], rmax1);
         atomic_max_i64(&t[6], c1 + 1);
         atomic_min_i64(&t[7], first);
 #pragma unroll
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) region_reduce4_kernel(const int *__restri
 #pragma unroll
                     for (int k = 0; k < NC; ++k) a1[k] = k < C ? (double)pl[(int64_t)k * n + (int64_t)r * W + c + j] : 0.0;
                 }
-                region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, ll[j], 1, r, c + j, r, c + j, c + j,
+                region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, ll[j], 1, r, c + j, r, r + 1, c + j, c + j,
                                   (long long)r * W + c + j, a1);
             }
         }
@@ -278,8 +278,104 @@ __global__ void __launch_bounds__(256) region_reduce4_kernel(const int *__restri
         }
         if (head && l > 0) {
             const long long L = 4ll * len, c0 = c, c1 = c + L - 1;
-            region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, l, L, (long long)r * L, (c0 + c1) * L / 2, r, c0, c1,
+            region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, l, L, (long long)r * L, (c0 + c1) * L / 2, r, r + 1, c0, c1,
                               (long long)r * W + c0, acc);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
+        const int l = tags[i];
+        if (l == 0) continue;
+        long long *t = gst + (int64_t)(l - 1) * 8;
+        atomicAdd((unsigned long long *)&t[0], (unsigned long long)lstat[i][0]);
+        atomicAdd((unsigned long long *)&t[1], (unsigned long long)lstat[i][1]);
+        atomicAdd((unsigned long long *)&t[2], (unsigned long long)lstat[i][2]);
+        atomic_min_i64(&t[3], lstat[i][3]);
+        atomic_min_i64(&t[4], lstat[i][4]);
+        atomic_max_i64(&t[5], lstat[i][5]);
+        atomic_max_i64(&t[6], lstat[i][6]);
+        atomic_min_i64(&t[7], lstat[i][7]);
+        if (NC > 0)
+            for (int k = 0; k < C; ++k) atomicAdd(&gsum[(int64_t)(l - 1) * C + k], lsum[i][k]);
+    }
+}
+
+// Column-run variant (W % 4 == 0): a lane owns 4 adjacent columns and walks DOWN COL_ROWS rows; it accumulates the
+// vertical run of equal labels in registers (area, row sum, plane sums in float64) and commits when the label
+// changes.  No cross-lane traffic at all; loads are int4 / float4 and coalesced along the row.
+constexpr int COL_ROWS = 32;
+
+template <int NC>
+__global__ void __launch_bounds__(256) region_reduce_col_kernel(const int *__restrict__ labels, const float *__restrict__ planes,
+                                                                 int C, int H, int W, int cap, long long *__restrict__ stats,
+                                                                 double *__restrict__ sums, int *__restrict__ overflow)
+{
+    __shared__ int tags[RED_SLOTS];
+    __shared__ long long lstat[RED_SLOTS][8];
+    __shared__ double lsum[NC > 0 ? RED_SLOTS : 1][RED_MAXC];
+    const int b = blockIdx.z;
+    const int64_t n = (int64_t)H * W;
+    const int *lab = labels + (int64_t)b * n;
+    const float *pl = NC > 0 ? planes + (int64_t)b * C * n : nullptr;
+    long long *gst = stats + (int64_t)b * cap * 8;
+    double *gsum = NC > 0 ? sums + (int64_t)b * cap * C : nullptr;
+    for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
+        tags[i] = 0;
+        lstat[i][0] = 0; lstat[i][1] = 0; lstat[i][2] = 0; lstat[i][3] = H; lstat[i][4] = W; lstat[i][5] = 0; lstat[i][6] = 0;
+        lstat[i][7] = 0x7FFFFFFFFFFFFFFFLL;
+        if (NC > 0)
+            for (int k = 0; k < RED_MAXC; ++k) lsum[i][k] = 0.0;
+    }
+    __syncthreads();
+    const RegionSlots ls{tags, lstat, lsum};
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int r0 = blockIdx.y * COL_ROWS, r1 = min(H, r0 + COL_ROWS);
+    if (c < W) {
+        int cur[4] = {0, 0, 0, 0}, start[4] = {0, 0, 0, 0};
+        long long area[4] = {0, 0, 0, 0}, srow[4] = {0, 0, 0, 0};
+        double acc[4][NC > 0 ? NC : 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < (NC > 0 ? NC : 1); ++k) acc[j][k] = 0.0;
+        for (int r = r0; r <= r1; ++r) {
+            int4 l4 = make_int4(0, 0, 0, 0);
+            float4 v[NC > 0 ? NC : 1];
+            if (r < r1) {
+                l4 = *reinterpret_cast<const int4 *>(lab + (int64_t)r * W + c);
+                if (NC > 0) {
+#pragma unroll
+                    for (int k = 0; k < NC; ++k)
+                        v[k] = k < C ? *reinterpret_cast<const float4 *>(pl + (int64_t)k * n + (int64_t)r * W + c)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            const int ll[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ll[j] != cur[j] || r == r1) {
+                    if (cur[j] > 0)
+                        region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, cur[j], area[j], srow[j], (long long)(c + j) * area[j],
+                                          start[j], start[j] + area[j], c + j, c + j, (long long)start[j] * W + c + j, acc[j]);
+                    cur[j] = r < r1 ? ll[j] : 0;
+                    start[j] = r;
+                    area[j] = 0;
+                    srow[j] = 0;
+#pragma unroll
+                    for (int k = 0; k < (NC > 0 ? NC : 1); ++k) acc[j][k] = 0.0;
+                }
+                if (r < r1 && ll[j] > 0) {
+                    area[j] += 1;
+                    srow[j] += r;
+                    if (NC > 0) {
+#pragma unroll
+                        for (int k = 0; k < NC; ++k) {
+                            const float4 f = v[k];
+                            acc[j][k] += (double)(j == 0 ? f.x : (j == 1 ? f.y : (j == 2 ? f.z : f.w)));
+                        }
+                    }
+                }
+            }
         }
     }
     __syncthreads();
@@ -337,7 +433,8 @@ __global__ void __launch_bounds__(256) merge_groups_kernel(const int *__restrict
                                                             const int *__restrict__ region_list, const int *__restrict__ n_list,
                                                             int *__restrict__ group_of, int *__restrict__ n_groups,
                                                             int *__restrict__ key_ws, int *__restrict__ first_ws,
-                                                            int *__restrict__ gid_ws, int H, int W, int cap, int list_cap)
+                                                            int *__restrict__ gid_ws, int H, int W, int cap, int list_cap,
+                                                            int keys_are_roots)
 {
     __shared__ int wsum[4];
     const int b = blockIdx.x;
@@ -358,7 +455,14 @@ __global__ void __launch_bounds__(256) merge_groups_kernel(const int *__restrict
             long long a = st[(int64_t)r * 8 + 0];
             if (a > 0) {
                 long long y = st[(int64_t)r * 8 + 1] / a, x = st[(int64_t)r * 8 + 2] / a;
-                if (y >= 0 && y < H && x >= 0 && x < W) key_k = dlab[y * W + x];
+                if (y >= 0 && y < H && x >= 0 && x < W) {
+                    key_k = dlab[y * W + x];
+                    if (keys_are_roots) {  // parent image of a union-find (-1 = background): walk to the root
+                        int q;
+                        while (key_k >= 0 && (q = dlab[key_k]) != key_k) key_k = q;
+                        key_k += 1;
+                    }
+                }
             }
         }
         key[k] = key_k;
@@ -605,14 +709,15 @@ int pcseg_region_reduce_n(const int32_t *labels, const int32_t *counts, const ui
     PCSEG_CHECK_LAUNCH();
     dim3 grid((H + RED_ROWS - 1) / RED_ROWS, B);
     const bool vec = (W % 4) == 0 && ((uintptr_t)labels % 16) == 0 && (!planes || ((uintptr_t)planes % 16) == 0);
+    const dim3 cgrid((W / 4 + 255) / 256, (H + COL_ROWS - 1) / COL_ROWS, B);
     if (vec && planes && C <= 5)
-        PCSEG_LAUNCH(region_reduce4_kernel<5>, grid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats, sums,
+        PCSEG_LAUNCH(region_reduce_col_kernel<5>, cgrid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats, sums,
                      overflow);
     else if (vec && planes)
-        PCSEG_LAUNCH(region_reduce4_kernel<8>, grid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats, sums,
+        PCSEG_LAUNCH(region_reduce_col_kernel<8>, cgrid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats, sums,
                      overflow);
     else if (vec)
-        PCSEG_LAUNCH(region_reduce4_kernel<0>, grid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats, sums,
+        PCSEG_LAUNCH(region_reduce_col_kernel<0>, cgrid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats, sums,
                      overflow);
     else if (planes)
         PCSEG_LAUNCH(region_reduce_kernel<true>, grid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats,
@@ -641,9 +746,9 @@ size_t pcseg_merge_groups_workspace_bytes(int B, int list_cap)
     return align_up(sizeof(int) * (size_t)B * list_cap) * 2 + align_up(sizeof(int) * (size_t)B * (list_cap + 1));
 }
 
-int pcseg_merge_groups(const int32_t *dilated_labels, const int64_t *stats, const int32_t *region_list, const int32_t *n_list,
-                       int32_t *group_of, int32_t *n_groups, int B, int H, int W, int cap, int list_cap, void *workspace,
-                       size_t workspace_bytes, pcseg_stream_t stream)
+int pcseg_merge_groups(const int32_t *dilated_labels, int keys_are_roots, const int64_t *stats, const int32_t *region_list,
+                       const int32_t *n_list, int32_t *group_of, int32_t *n_groups, int B, int H, int W, int cap, int list_cap,
+                       void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
 {
     PCSEG_REQUIRE(dilated_labels && stats && region_list && n_list && group_of && n_groups && workspace && cap >= 1 &&
                       list_cap >= 1 && check_shape(B, H, W),
@@ -657,7 +762,8 @@ int pcseg_merge_groups(const int32_t *dilated_labels, const int64_t *stats, cons
         return PCSEG_ERR_WORKSPACE;
     }
     PCSEG_LAUNCH(merge_groups_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dilated_labels,
-                       (const long long *)stats, region_list, n_list, group_of, n_groups, key, first, gid, H, W, cap, list_cap);
+                       (const long long *)stats, region_list, n_list, group_of, n_groups, key, first, gid, H, W, cap, list_cap,
+                       keys_are_roots);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

@@ -581,7 +581,9 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                          int32_t *tie_flags, int B, int H, int W, int mode, void *workspace, size_t workspace_bytes,
                          pcseg_stream_t stream)
 {
-    PCSEG_REQUIRE(img && markers && mask && out && workspace && check_shape(B, H, W) && mode >= 0 && mode <= 2, "bad arguments");
+    PCSEG_REQUIRE(img && markers && mask && out && workspace && check_shape(B, H, W) && mode >= 0 && (mode & 3) <= 2 && mode < 8, "bad arguments");
+    const bool verify = (mode & 4) != 0;  // also run the explicit per-pixel proof check (implied by the component test)
+    mode &= 3;
     PCSEG_REQUIRE(frame_stride == 0 || frame_stride >= (int64_t)H * W, "frame_stride smaller than a frame");
     if (frame_stride == 0) frame_stride = (int64_t)H * W;
     hipStream_t s = (hipStream_t)stream;
@@ -665,9 +667,11 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         PCSEG_CHECK_HIP(hipMemsetAsync(flags2, 0, sizeof(int) * B, s));
         rc = assign_labels((const unsigned *)L, (const int *)nullptr, flags);
         if (rc) return rc;
-        PCSEG_LAUNCH(ws_check_kernel<unsigned>, pgrid, dim3(256), 0, s, (const unsigned *)L, (const int *)out, markers, mask,
-                     (const int *)nullptr, flags, H, W);
-        PCSEG_CHECK_LAUNCH();
+        if (verify) {
+            PCSEG_LAUNCH(ws_check_kernel<unsigned>, pgrid, dim3(256), 0, s, (const unsigned *)L, (const int *)out, markers, mask,
+                         (const int *)nullptr, flags, H, W);
+            PCSEG_CHECK_LAUNCH();
+        }
         int any_flag = 0;
         {
             // flags -> host: is the second-level pass needed at all?
@@ -694,9 +698,11 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             PCSEG_CHECK_LAUNCH();
             rc = assign_labels((const unsigned long long *)K64, (const int *)flags, flags2);
             if (rc) return rc;
-            PCSEG_LAUNCH(ws_check_kernel<unsigned long long>, pgrid, dim3(256), 0, s, (const unsigned long long *)K64,
-                         (const int *)out, markers, mask, (const int *)flags, flags2, H, W);
-            PCSEG_CHECK_LAUNCH();
+            if (verify) {
+                PCSEG_LAUNCH(ws_check_kernel<unsigned long long>, pgrid, dim3(256), 0, s, (const unsigned long long *)K64,
+                             (const int *)out, markers, mask, (const int *)flags, flags2, H, W);
+                PCSEG_CHECK_LAUNCH();
+            }
         }
     }
     if (tie_flags) PCSEG_CHECK_HIP(hipMemcpyAsync(tie_flags, flags2, sizeof(int) * B, hipMemcpyDeviceToDevice, s));

@@ -250,8 +250,22 @@ def watershed(img, markers, mask, mode=0):
     return out, flags
 
 
-def merge_groups(dilated_labels, stats, region_list, n_list):
-    """get_merged_regions grouping (tiff_analysis.py:843-878): group id per list entry, 0 = dropped."""
+def dilated_roots(x, value_bits, radius):
+    """components of binary_dilation(((value_bits >> x) & 1), disk(radius)) as a union-find parent image (A6)."""
+    x = _req(x, torch.uint8, 3)
+    B, H, W = x.shape
+    lib = _lib.load()
+    roots = torch.empty((B, H, W), dtype=torch.int32, device=x.device)
+    nbytes = lib.pcseg_dilate_ccl_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, x.device)
+    _lib.check(lib.pcseg_dilate_ccl_roots_u8(_ptr(x), ctypes.c_uint64(int(value_bits)), int(radius), _ptr(roots), B, H, W,
+                                             _ptr(ws), nbytes, _stream()), "dilated_roots")
+    return roots
+
+
+def merge_groups(dilated_labels, stats, region_list, n_list, roots=False):
+    """get_merged_regions grouping (tiff_analysis.py:843-878): group id per list entry, 0 = dropped.
+    roots=True: `dilated_labels` is the parent image of dilated_roots()."""
     dl = _req(dilated_labels, torch.int32, 3)
     stats = _req(stats, torch.int64, 3)
     region_list = _req(region_list, torch.int32, 2)
@@ -264,7 +278,7 @@ def merge_groups(dilated_labels, stats, region_list, n_list):
     n_groups = torch.zeros((B,), dtype=torch.int32, device=dl.device)
     nbytes = lib.pcseg_merge_groups_workspace_bytes(B, list_cap)
     ws = _ws(nbytes, dl.device)
-    _lib.check(lib.pcseg_merge_groups(_ptr(dl), _ptr(stats), _ptr(region_list), _ptr(n_list), _ptr(group_of),
+    _lib.check(lib.pcseg_merge_groups(_ptr(dl), int(bool(roots)), _ptr(stats), _ptr(region_list), _ptr(n_list), _ptr(group_of),
                                       _ptr(n_groups), B, H, W, cap, list_cap, _ptr(ws), nbytes, _stream()), "merge_groups")
     return group_of, n_groups
 

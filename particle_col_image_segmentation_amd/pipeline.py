@@ -81,11 +81,11 @@ class FramePipeline:
                     bits = bits_all
                 if bits == 0:
                     continue
-                dil = ops.dilate_disk(z, bits, ta.CELL_CLUSTER_DISTANCE_THRESHOLD // 2)
-                dl, _ = ops.label_bool8(dil)
+                # dilated components as union-find roots on the 1-bit image: grouping only needs "same component"
+                dl = ops.dilated_roots(z, bits, ta.CELL_CLUSTER_DISTANCE_THRESHOLD // 2)
                 lst = res["region_list"][:, s].contiguous()
                 nl = res["n_list"][:, s].contiguous()
-                gof, ng = ops.merge_groups(dl, stats, lst, nl)
+                gof, ng = ops.merge_groups(dl, stats, lst, nl, roots=True)
                 gst = ops.group_reduce(stats, lst, nl, gof, ng, H, W)
                 groups[s] = {"group_of": gof, "n_groups": ng, "group_stats": gst}
             res["groups"] = groups

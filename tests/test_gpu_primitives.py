@@ -210,14 +210,14 @@ def test_local_maxima(ops, primitives):
         np.testing.assert_array_equal(host(markers)[i], orc.label(lm))
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 4])
 def test_watershed_golden(ops, primitives, mode):
     n_flagged = 0
     for c in golden_cases(primitives, "ws"):
         out, flags = ops.watershed(one(c["img"]), one(c["markers"]), one(c["mask"]), mode=mode)
         np.testing.assert_array_equal(host(out)[0], c["out"])
         n_flagged += int(flags[0])
-    if mode == 0:
+    if mode in (0, 4):
         assert n_flagged > 0  # quantised cases must have gone through the exact path
 
 
@@ -230,6 +230,8 @@ def test_watershed_parallel_path_is_proven(ops):
     mk = np.stack([r["markers"] for r in refs])
     ms = np.stack([r["binary_mask"] for r in refs])
     out, flags = ops.watershed(dev(bm), dev(mk), dev(ms), mode=2)
+    out_v, flags_v = ops.watershed(dev(bm), dev(mk), dev(ms), mode=6)  # + explicit per-pixel proof check
+    assert torch.equal(flags, flags_v) and torch.equal(out, out_v)
     proven = 0
     for i in range(3):
         if int(flags[i]) == 0:
@@ -279,6 +281,15 @@ def test_merge_groups(ops):
         rl[i, :len(l)] = l
     n_list = torch.tensor([len(l) for l in lists], dtype=torch.int32).cuda()
     group_of, n_groups = ops.merge_groups(dl, stats, dev(rl), n_list)
+    # fused path: bit dilation + union-find roots, no numbering pass
+    roots = ops.dilated_roots(dev(cm), (1 << 1) | (1 << 2), 2)
+    np.testing.assert_array_equal(host(roots) >= 0, host(dil).astype(bool))
+    g2, n2 = ops.merge_groups(roots, stats, dev(rl), n_list, roots=True)
+    assert torch.equal(g2, group_of) and torch.equal(n2, n_groups)
+    for rad in (0, 1, 3, 5):
+        rr = ops.dilated_roots(dev(cm), 1 << 1, rad)
+        for i in range(2):
+            np.testing.assert_array_equal(host(rr)[i] >= 0, orc.binary_dilation_disk(cm[i] == 1, rad))
     for i in range(2):
         groups, _ = orc.get_merged_regions((cm[i] == 1) | (cm[i] == 2), regs_all[i])
         exp = np.zeros(len(lists[i]), np.int32)
