@@ -93,7 +93,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)  # torchrun, also with one rank
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -113,7 +114,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     lib.pcseg_timing_enable(1)
@@ -130,7 +131,7 @@ def main():
     buf = ctypes.create_string_buffer(nbytes + 16)
     lib.pcseg_timing_report(buf, nbytes + 16)
     lib.pcseg_timing_enable(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -184,7 +185,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, args.cpu_frames)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
