@@ -176,31 +176,32 @@ __global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict
         const int j = idx / W, c = idx % W;
         const int64_t gi = fbase + (int64_t)(r0 + j) * W + c;
         const uint16_t *gr = g + j * W;
-        long long best;
+        // 32-bit arithmetic is exact here: g <= 32767 and k < 32768, so g*g + k*k < 2^31
+        unsigned best;
         if (!epi.wants(gi)) {
             best = 0;
         } else {
             unsigned g0 = gr[c];
-            best = g0 == G_INF ? (1ll << 40) : (long long)g0 * g0;
+            best = g0 == G_INF ? 0xFFFFFFFFu : g0 * g0;
             // four offsets per trip: the 8 LDS reads are issued together; offsets past the exit point are still true
             // candidates (g^2 + k^2 of a real pixel), so the minimum stays exact
-            for (int k = 1; k <= kmax && (long long)k * k < best; k += 4) {
+            for (int k = 1; k <= kmax && (unsigned)(k * k) < best; k += 4) {
                 if (c - k < 0 && c + k >= W) break;
                 unsigned gl[4], gq[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    gl[j] = c - k - j >= 0 ? gr[c - k - j] : G_INF;
-                    gq[j] = c + k + j < W ? gr[c + k + j] : G_INF;
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    gl[j2] = c - k - j2 >= 0 ? gr[c - k - j2] : G_INF;
+                    gq[j2] = c + k + j2 < W ? gr[c + k + j2] : G_INF;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const long long kk = (long long)(k + j) * (k + j);
-                    if (gl[j] != G_INF) best = min(best, (long long)gl[j] * gl[j] + kk);
-                    if (gq[j] != G_INF) best = min(best, (long long)gq[j] * gq[j] + kk);
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    const unsigned kk = (unsigned)((k + j2) * (k + j2));
+                    if (gl[j2] != G_INF) best = min(best, gl[j2] * gl[j2] + kk);
+                    if (gq[j2] != G_INF) best = min(best, gq[j2] * gq[j2] + kk);
                 }
             }
         }
-        epi.store(gi, best, anybg, r0 + j, c, cnt);
+        epi.store(gi, best == 0xFFFFFFFFu ? (1ll << 40) : (long long)best, anybg, r0 + j, c, cnt);
     }
     if (count) {
         for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);

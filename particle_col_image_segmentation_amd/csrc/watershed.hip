@@ -227,7 +227,7 @@ constexpr int UF_TW = 64, UF_TH = 32, UF_SW = UF_TW + 2, UF_SH = UF_TH + 2;
 template <typename KeyT>
 __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const KeyT *__restrict__ K, const int *__restrict__ F,
                                                           const int *__restrict__ frame_flags, int *__restrict__ parent,
-                                                          int H, int W)
+                                                          uint8_t *__restrict__ minmask, int H, int W)
 {
     __shared__ KeyT sK[UF_SH * UF_SW];
     __shared__ int par[UF_TH * UF_TW];
@@ -247,19 +247,23 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const KeyT *__restrict_
     }
     __syncthreads();
     for (int t = threadIdx.x; t < UF_TH * UF_TW; t += 256) {
-        if (par[t] < 0) continue;
         const int lr = t / UF_TW, lc = t % UF_TW;
         const int r = r0 + lr, c = c0 + lc;
         if (r >= H || c >= W) continue;
-        if (F[fbase + (int64_t)r * W + c] != 0) continue;  // seeds take no label from neighbours
-        const int i = (lr + 1) * UF_SW + lc + 1;
-        const KeyT ku = sK[i - UF_SW], kl = sK[i - 1], kr = sK[i + 1], kd = sK[i + UF_SW];
-        const KeyT m = min(min(ku, kd), min(kl, kr));
-        if (m == KINF) continue;
-        if (ku == m && lr > 0) unite_lds(par, t, t - UF_TW);
-        if (kl == m && lc > 0) unite_lds(par, t, t - 1);
-        if (kr == m && lc < UF_TW - 1) unite_lds(par, t, t + 1);
-        if (kd == m && lr < UF_TH - 1) unite_lds(par, t, t + UF_TW);
+        // which neighbours hold the minimum neighbour key (bit0 up, 1 left, 2 right, 3 down); 0 for seeds / unreachable.
+        // Written for the border pass, which then needs two bytes per cross-tile pair instead of ten keys.
+        uint8_t m8 = 0;
+        if (par[t] >= 0 && F[fbase + (int64_t)r * W + c] == 0) {  // seeds take no label from neighbours
+            const int i = (lr + 1) * UF_SW + lc + 1;
+            const KeyT ku = sK[i - UF_SW], kl = sK[i - 1], kr = sK[i + 1], kd = sK[i + UF_SW];
+            const KeyT m = min(min(ku, kd), min(kl, kr));
+            if (m != KINF) m8 = (ku == m ? 1 : 0) | (kl == m ? 2 : 0) | (kr == m ? 4 : 0) | (kd == m ? 8 : 0);
+        }
+        minmask[fbase + (int64_t)r * W + c] = m8;
+        if ((m8 & 1) && lr > 0) unite_lds(par, t, t - UF_TW);
+        if ((m8 & 2) && lc > 0) unite_lds(par, t, t - 1);
+        if ((m8 & 4) && lc < UF_TW - 1) unite_lds(par, t, t + 1);
+        if ((m8 & 8) && lr < UF_TH - 1) unite_lds(par, t, t + UF_TW);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < UF_TH * UF_TW; t += 256) {
@@ -274,25 +278,9 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const KeyT *__restrict_
     }
 }
 
-// is q one of the minimum-key neighbours of the non-seed pixel p?  (keys read from global memory)
-template <typename KeyT>
-__device__ __forceinline__ bool ws_is_min_nbr(const KeyT *__restrict__ K, const int *__restrict__ F, int64_t fbase, int pr,
-                                              int pc, int qr, int qc, int H, int W)
-{
-    const KeyT KINF = ~(KeyT)0;
-    const int64_t p = fbase + (int64_t)pr * W + pc;
-    if ((unsigned)(K[p] >> (8 * sizeof(KeyT) - 32)) == WS_INF || F[p] != 0) return false;
-    const KeyT ku = pr > 0 ? K[p - W] : KINF, kd = pr + 1 < H ? K[p + W] : KINF;
-    const KeyT kl = pc > 0 ? K[p - 1] : KINF, kr = pc + 1 < W ? K[p + 1] : KINF;
-    const KeyT m = min(min(ku, kd), min(kl, kr));
-    if (m == KINF) return false;
-    return K[fbase + (int64_t)qr * W + qc] == m;
-}
-
-template <typename KeyT>
-__global__ void __launch_bounds__(256) ws_uf_border_kernel(const KeyT *__restrict__ K, const int *__restrict__ F,
-                                                            const int *__restrict__ frame_flags, int *__restrict__ parent,
-                                                            int H, int W)
+// cross-tile links from the neighbour masks the tile pass left behind
+__global__ void __launch_bounds__(256) ws_uf_border_kernel(const uint8_t *__restrict__ minmask, const int *__restrict__ frame_flags,
+                                                            int *__restrict__ parent, int H, int W)
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -305,10 +293,9 @@ __global__ void __launch_bounds__(256) ws_uf_border_kernel(const KeyT *__restric
     const int64_t fbase = (int64_t)b * H * W;
     int *par = parent + fbase;
     const int p = r * W + c;
-    if (top && (ws_is_min_nbr(K, F, fbase, r, c, r - 1, c, H, W) || ws_is_min_nbr(K, F, fbase, r - 1, c, r, c, H, W)))
-        unite_glb(par, p, p - W);
-    if (left && (ws_is_min_nbr(K, F, fbase, r, c, r, c - 1, H, W) || ws_is_min_nbr(K, F, fbase, r, c - 1, r, c, H, W)))
-        unite_glb(par, p, p - 1);
+    const uint8_t mp = minmask[fbase + p];
+    if (top && ((mp & 1) || (minmask[fbase + p - W] & 8))) unite_glb(par, p, p - W);
+    if (left && ((mp & 2) || (minmask[fbase + p - 1] & 4))) unite_glb(par, p, p - 1);
 }
 
 // flatten + seeds publish their marker id at the root: hi = max id, nlo = max (INT_MAX - id)  (both start at 0)
@@ -573,7 +560,7 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
     if (!check_shape(B, H, W)) return 0;
     size_t n = (size_t)B * H * W;
     int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
-    return 5 * align_up(n * 4) + 2 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + 2 * align_up(sizeof(int) * B) +
+    return 5 * align_up(n * 4) + align_up(n) + 2 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + 2 * align_up(sizeof(int) * B) +
            align_up(n * 8) + align_up(n * 4);
 }
 
@@ -603,6 +590,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     int *uf_parent = cv.take<int>(n);
     int *uf_hi = cv.take<int>(n);
     int *uf_nlo = cv.take<int>(n);
+    uint8_t *uf_mask = cv.take<uint8_t>(n);
     if (!cv.ok()) {
         set_error("watershed: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
@@ -650,10 +638,9 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             PCSEG_CHECK_HIP(hipMemsetAsync(uf_hi, 0, sizeof(int) * n, s));
             PCSEG_CHECK_HIP(hipMemsetAsync(uf_nlo, 0, sizeof(int) * n, s));
             PCSEG_LAUNCH(ws_uf_tile_kernel<KeyT>, ugrid, dim3(256), 0, s, (const KeyT *)keys, (const int *)out, frame_flags,
-                         uf_parent, H, W);
+                         uf_parent, uf_mask, H, W);
             PCSEG_CHECK_LAUNCH();
-            PCSEG_LAUNCH(ws_uf_border_kernel<KeyT>, pgrid, dim3(256), 0, s, (const KeyT *)keys, (const int *)out, frame_flags,
-                         uf_parent, H, W);
+            PCSEG_LAUNCH(ws_uf_border_kernel, pgrid, dim3(256), 0, s, (const uint8_t *)uf_mask, frame_flags, uf_parent, H, W);
             PCSEG_CHECK_LAUNCH();
             PCSEG_LAUNCH(ws_uf_seed_kernel, lgrid, dim3(256), 0, s, uf_parent, (const int *)out, frame_flags, uf_hi, uf_nlo,
                          (int64_t)H * W);
