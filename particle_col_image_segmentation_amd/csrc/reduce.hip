@@ -2,12 +2,11 @@
 // region classification / cluster cell counts (A3/A4 tail) and the proximity
 // merge grouping (A6 tail).
 //
-// The reduction walks rows: one wave covers 64 consecutive pixels of a row,
-// finds label runs with a ballot, and the head lane of each run adds closed-form
-// run sums (length, row*length, column arithmetic series, bbox) -- integers only,
-// so the result is independent of the order of the atomics.  A 256-slot
-// direct-mapped LDS table absorbs the hot labels (background, particle) of the
-// block's rows and is flushed once per block.
+// Main kernel (W % 4 == 0): a lane owns 4 adjacent columns and walks down 32 rows, accumulating each vertical run
+// of equal labels in registers (int4 / float4 loads, no cross-lane traffic) and committing it when the label
+// changes.  All table columns are integers, so the result does not depend on the order of the atomics; a 256-slot
+// direct-mapped LDS table absorbs the hot labels (background, particle) and is flushed once per block.  The generic
+// fallback walks rows: one wave per 64-pixel row segment, label runs from a ballot, closed-form run sums.
 #include "common.h"
 
 namespace pcseg {
@@ -149,9 +148,7 @@ __global__ void __launch_bounds__(256) region_reduce_kernel(const int *__restric
     }
 }
 
-// Vectorised variant for W % 4 == 0: one lane owns 4 consecutive pixels (int4 labels, float4 per plane), a wave owns
-// a 256-pixel row segment.  Lanes whose 4 pixels share one label join the wave-level run reduction (4x fewer
-// shuffles per pixel); lanes that straddle a label boundary commit their pixels one by one.
+// shared commit step of the reduce kernels: LDS slot if the label owns (or can claim) it, else global atomics
 struct RegionSlots {
     int *tags;
     long long (*lstat)[8];
@@ -194,109 +191,6 @@ __device__ __forceinline__ void region_commit(const RegionSlots &ls, long long *
 #pragma unroll
         for (int k = 0; k < NC; ++k)
             if (k < C) atomicAdd(&gsum[(int64_t)(l - 1) * C + k], acc[k]);
-    }
-}
-
-template <int NC>
-__global__ void __launch_bounds__(256) region_reduce4_kernel(const int *__restrict__ labels, const float *__restrict__ planes,
-                                                              int C, int H, int W, int cap, long long *__restrict__ stats,
-                                                              double *__restrict__ sums, int *__restrict__ overflow)
-{
-    __shared__ int tags[RED_SLOTS];
-    __shared__ long long lstat[RED_SLOTS][8];
-    __shared__ double lsum[NC > 0 ? RED_SLOTS : 1][RED_MAXC];
-    const int b = blockIdx.y;
-    const int64_t n = (int64_t)H * W;
-    const int *lab = labels + (int64_t)b * n;
-    const float *pl = NC > 0 ? planes + (int64_t)b * C * n : nullptr;
-    long long *gst = stats + (int64_t)b * cap * 8;
-    double *gsum = NC > 0 ? sums + (int64_t)b * cap * C : nullptr;
-    for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
-        tags[i] = 0;
-        lstat[i][0] = 0; lstat[i][1] = 0; lstat[i][2] = 0; lstat[i][3] = H; lstat[i][4] = W; lstat[i][5] = 0; lstat[i][6] = 0;
-        lstat[i][7] = 0x7FFFFFFFFFFFFFFFLL;
-        if (NC > 0)
-            for (int k = 0; k < RED_MAXC; ++k) lsum[i][k] = 0.0;
-    }
-    __syncthreads();
-    const RegionSlots ls{tags, lstat, lsum};
-    const int lane = lane_id(), wid = threadIdx.x >> 6;
-    const int row0 = blockIdx.x * RED_ROWS;
-    const int segs = (W + 255) / 256;
-    for (int item = wid; item < RED_ROWS * segs; item += 4) {
-        const int r = row0 + item / segs;
-        if (r >= H) break;
-        const int c = (item % segs) * 256 + lane * 4;
-        const bool inb = c < W;  // W % 4 == 0: the 4 pixels are all inside or all outside
-        int4 l4 = make_int4(0, 0, 0, 0);
-        if (inb) l4 = *reinterpret_cast<const int4 *>(lab + (int64_t)r * W + c);
-        const bool uniform = l4.x == l4.y && l4.y == l4.z && l4.z == l4.w;
-        const int l = uniform ? l4.x : 0;
-        double acc[NC > 0 ? NC : 1];
-        if (NC > 0) {
-#pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                acc[k] = 0.0;
-                if (k < C && inb && (l4.x | l4.y | l4.z | l4.w) != 0) {
-                    float4 v = *reinterpret_cast<const float4 *>(pl + (int64_t)k * n + (int64_t)r * W + c);
-                    if (uniform) acc[k] = (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-                    else {
-                        // boundary lane: commit pixel by pixel below, keep the raw values in acc via bit tricks is not
-                        // possible (4 values) -> re-read there
-                    }
-                }
-            }
-        }
-        if (inb && !uniform) {
-            const int ll[4] = {l4.x, l4.y, l4.z, l4.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (ll[j] <= 0) continue;
-                double a1[NC > 0 ? NC : 1];
-                if (NC > 0) {
-#pragma unroll
-                    for (int k = 0; k < NC; ++k) a1[k] = k < C ? (double)pl[(int64_t)k * n + (int64_t)r * W + c + j] : 0.0;
-                }
-                region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, ll[j], 1, r, c + j, r, r + 1, c + j, c + j,
-                                  (long long)r * W + c + j, a1);
-            }
-        }
-        const int lprev = __shfl_up(l, 1);
-        const bool head = (lane == 0) || (l != lprev);
-        const unsigned long long heads = __ballot(head);
-        const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1));
-        const int len = after ? __ffsll((long long)after) : (64 - lane);
-        if (NC > 0) {
-            const int remain = len - 1;
-            for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-                for (int k = 0; k < NC; ++k) {
-                    double t = __shfl_down(acc[k], off);
-                    if (k < C && off <= remain) acc[k] += t;
-                }
-            }
-        }
-        if (head && l > 0) {
-            const long long L = 4ll * len, c0 = c, c1 = c + L - 1;
-            region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, l, L, (long long)r * L, (c0 + c1) * L / 2, r, r + 1, c0, c1,
-                              (long long)r * W + c0, acc);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
-        const int l = tags[i];
-        if (l == 0) continue;
-        long long *t = gst + (int64_t)(l - 1) * 8;
-        atomicAdd((unsigned long long *)&t[0], (unsigned long long)lstat[i][0]);
-        atomicAdd((unsigned long long *)&t[1], (unsigned long long)lstat[i][1]);
-        atomicAdd((unsigned long long *)&t[2], (unsigned long long)lstat[i][2]);
-        atomic_min_i64(&t[3], lstat[i][3]);
-        atomic_min_i64(&t[4], lstat[i][4]);
-        atomic_max_i64(&t[5], lstat[i][5]);
-        atomic_max_i64(&t[6], lstat[i][6]);
-        atomic_min_i64(&t[7], lstat[i][7]);
-        if (NC > 0)
-            for (int k = 0; k < C; ++k) atomicAdd(&gsum[(int64_t)(l - 1) * C + k], lsum[i][k]);
     }
 }
 

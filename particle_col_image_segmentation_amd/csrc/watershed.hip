@@ -8,12 +8,15 @@
 // because every comparison that decides "a pops before b" for L(a) < L(b) is a
 // strict value comparison.  Hence the pixel that labels q (its first-popped
 // neighbour) has L = min over q's neighbours, and
-//   * parallel path: (1) L by tile-iterated relaxation, (2) label propagation
-//     "take the label of a labelled neighbour with L == Lmin", (3) a proof
-//     check: for every non-seed reachable pixel ALL neighbours with L == Lmin
-//     carry the pixel's label.  If the check holds for the whole frame the
-//     result equals the sequential flood's for ANY tie-breaking (induction over
-//     the pop order), so the frame is bit-exact without emulating the heap;
+//   * parallel path: (1) L by tile-iterated relaxation, (2) labels by a
+//     union-find over the links "pixel -- each neighbour with L == Lmin", (3) a
+//     proof condition: for every non-seed reachable pixel ALL neighbours with
+//     L == Lmin carry the pixel's label (equivalently: no union-find component
+//     holds two marker ids).  If it holds for the whole frame the result equals
+//     the sequential flood's for ANY tie-breaking (induction over the pop
+//     order), so the frame is bit-exact without emulating the heap;
+//   * frames that fail get a second-level order (L, K2) -- see below -- and the
+//     same union-find on the refined keys;
 //   * frames that fail the check (equal-valued bottlenecks or seeds between two
 //     basins -- ubiquitous in quantised probability maps) are recomputed by an
 //     exact emulation of the reference's binary heap, one workgroup per frame.
@@ -92,15 +95,6 @@ __device__ __forceinline__ void ws_store_tile(const T *s, T *__restrict__ g, int
     }
 }
 
-__device__ __forceinline__ void ws_mark_neighbours(uint8_t *dirty_out, int b, int tx, int ty, int tilesX, int tilesY)
-{
-    uint8_t *d = dirty_out + (int64_t)b * tilesX * tilesY;
-    if (tx > 0) d[ty * tilesX + tx - 1] = 1;
-    if (tx + 1 < tilesX) d[ty * tilesX + tx + 1] = 1;
-    if (ty > 0) d[(ty - 1) * tilesX + tx] = 1;
-    if (ty + 1 < tilesY) d[(ty + 1) * tilesX + tx] = 1;
-}
-
 // After a tile converged: wave e compares edge e of the tile (0 top, 1 bottom, 2 left, 3 right) with what is still in
 // global memory and marks only the neighbour that shares a CHANGED edge.  Must run BEFORE the tile is stored.
 template <typename T>
@@ -160,65 +154,7 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restric
     if (threadIdx.x == 0) *any_changed = 1;
 }
 
-// (2) label propagation along "labelled neighbour whose key equals the minimum key of the neighbours".
-// KeyT = unsigned: key = L;  KeyT = unsigned long long: key = (L << 32) | K2 (second-level order, see below)
-template <typename KeyT>
-__global__ void __launch_bounds__(256) ws_propagate_kernel(const KeyT *__restrict__ K, int *__restrict__ F,
-                                                            const int *__restrict__ frame_flags,
-                                                            const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
-                                                            int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
-{
-    __shared__ KeyT sK[WS_N];
-    __shared__ int sF[WS_N];
-    __shared__ uint8_t sC[WS_N];  // which neighbours hold the minimum neighbour key: bit0 up, 1 left, 2 right, 3 down
-    const KeyT KINF = ~(KeyT)0;
-    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
-    if (frame_flags && frame_flags[b] == 0) return;
-    if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
-    const int r0 = ty * WS_T, c0 = tx * WS_T;
-    const int64_t fbase = (int64_t)b * H * W;
-    ws_load_tile(sK, K + fbase, r0, c0, H, W, KINF);
-    ws_load_tile(sF, (const int *)F + fbase, r0, c0, H, W, 0);
-    __syncthreads();
-    for (int t = threadIdx.x; t < WS_T * WS_T; t += 256) {
-        int i = (t / WS_T + 1) * WS_P + t % WS_T + 1;
-        uint8_t m8 = 0;
-        if ((unsigned)(sK[i] >> (8 * sizeof(KeyT) - 32)) != WS_INF) {
-            KeyT lu = sK[i - WS_P], ll = sK[i - 1], lr = sK[i + 1], ld = sK[i + WS_P];
-            KeyT m = min(min(lu, ld), min(ll, lr));
-            m8 = (lu == m ? 1 : 0) | (ll == m ? 2 : 0) | (lr == m ? 4 : 0) | (ld == m ? 8 : 0);
-        }
-        sC[i] = m8;
-    }
-    __syncthreads();
-    const SweepLine ln = ws_line();
-    // the neighbour BEHIND the sweep direction: left for w0, right for w1, up for w2, down for w3
-    const int w = threadIdx.x >> 6;
-    const uint8_t behind = w == 0 ? 2 : (w == 1 ? 4 : (w == 2 ? 1 : 8));
-    bool changed_any = false;
-    for (int iter = 0; iter < 100000; ++iter) {
-        bool changed = false;
-        int prev = sF[ln.start];
-        int i = ln.start;
-#pragma unroll 8
-        for (int k = 0; k < WS_T; ++k) {
-            i += ln.step;
-            int f = sF[i];
-            if (f == 0 && prev != 0 && (sC[i] & behind)) { sF[i] = prev; f = prev; changed = true; }
-            prev = f;
-        }
-        if (!__syncthreads_or(changed)) break;
-        changed_any = true;
-    }
-    if (!changed_any) return;
-    ws_store_tile(sF, F + fbase, r0, c0, H, W);
-    if (threadIdx.x == 0) {
-        ws_mark_neighbours(dirty_out, b, tx, ty, tilesX, tilesY);
-        *any_changed = 1;
-    }
-}
-
-// (2') label assignment by union-find instead of wavefronts: every non-seed reachable pixel is united with ALL its
+// (2) label assignment by union-find: every non-seed reachable pixel is united with ALL its
 // neighbours that hold the minimum neighbour key.  If no pixel has minimum-key neighbours in two basins (the proof
 // check's premise) the components are exactly the basins, each holding the seeds of one marker; a component that
 // holds two different marker ids flags the frame instead.  One LDS tile pass + one border pass + flatten, like A2.
