@@ -31,9 +31,10 @@ CHAIN_BYTES_PER_PIXEL = 28  # 5 x f32 in + int32 class-CC mask +
 KERNEL_BYTES_PER_PIXEL = {
     "argmax_kernel": 21.0, "median5_kernel": 2.0, "ccl_tile_kernel": 5.0, "ccl_border_kernel": 0.0,
     "ccl_flatten_count_kernel": 8.0, "ccl_assign_kernel": 4.0, "ccl_relabel_kernel": 8.0, "ccl_flatten_kernel": 8.0,
-    "region_reduce_kernel": 24.0, "edt_bits_kernel": 1.0, "edt_row_kernel": 4.0, "ws_init_kernel": 21.0,
-    "ws_relax_kernel": 12.0, "ws_propagate_kernel": 12.0, "ws_check_kernel": 8.0, "ws_exact_kernel": 21.0,
-    "locmax_candidates_kernel": 8.0, "locmax_bad_kernel": 8.0,
+    "region_reduce_kernel": 24.0, "region_reduce_col_kernel": 24.0, "edt_bits_kernel": 1.0, "edt_row_kernel": 4.0,
+    "ws_init_kernel": 21.0, "ws_relax_kernel": 12.0, "ws_k2_relax_kernel": 12.0, "ws_uf_tile_kernel": 13.0,
+    "ws_uf_border_kernel": 0.0, "ws_uf_seed_kernel": 8.0, "ws_uf_assign_kernel": 12.0, "ws_check_kernel": 8.0,
+    "ws_exact_kernel": 21.0, "locmax_candidates_kernel": 8.0, "locmax_bad_kernel": 8.0,
 }
 
 
@@ -118,6 +119,7 @@ def main():
             dist.barrier()
 
     lib.pcseg_timing_enable(1)
+    lib.pcseg_watershed_counters(None, 1)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -157,7 +159,14 @@ def main():
         short = dom_name.split("<")[0].split(" ")[0].strip("()")
         bpp = KERNEL_BYTES_PER_PIXEL.get(short, float("nan"))
         avg_s = dom_ms / dom_calls / 1e3
-        achieved = bpp * B * H * W / avg_s / 1e9
+        units = float(B * H * W)  # pixels one launch processes
+        if short == "ws_relax_kernel":
+            # the relaxation only touches dirty tiles: count the 64x64 tiles it really processed
+            cnt = (ctypes.c_int64 * 4)()
+            lib.pcseg_watershed_counters(cnt, 0)
+            if cnt[1]:
+                units = 4096.0 * cnt[0] / cnt[1]
+        achieved = bpp * units / avg_s / 1e9
         total_kernel_ms = sum(ms for _, ms in kernels.values())
         value = world * B * H * W * args.steps / elapsed / 1e6
         traffic = None
@@ -175,6 +184,7 @@ def main():
                        "tie_fallback_frames_last_step": tie_frames, "gathered_roi_rows": n_rois},
             "roofline": {"bound": "hbm", "kernel": dom_name, "launches_per_step": dom_calls / args.steps,
                          "avg_launch_us": round(1e6 * avg_s, 2), "algorithmic_bytes_per_pixel": bpp,
+                         "pixels_per_launch": round(units),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "share_of_kernel_time": round(dom_ms / total_kernel_ms, 4),

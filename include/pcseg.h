@@ -164,6 +164,9 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
  * device int32[B] (may be NULL).
  * frame_stride: as for pcseg_edt_sq_lt_f32 (0 = H*W). */
 size_t pcseg_watershed_workspace_bytes(int B, int H, int W);
+/* measurement aid: out[0] = 64x64 tiles the minimax relaxation actually processed (dirty tiles over all rounds),
+ * out[1] = relaxation launches, out[2] = watershed calls since the last reset (process-wide). */
+void pcseg_watershed_counters(int64_t *out, int reset);
 int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *markers, const uint8_t *mask,
                          int32_t *out, int32_t *tie_flags, int B, int H, int W, int mode,
                          void *workspace, size_t workspace_bytes, pcseg_stream_t stream);

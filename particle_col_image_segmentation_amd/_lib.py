@@ -45,6 +45,7 @@ SIGNATURES = {
     "pcseg_local_maxima_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_local_maxima_i32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_watershed_workspace_bytes": (c_size_t, [_I, _I, _I]),
+    "pcseg_watershed_counters": (None, [_P, _I]),
     "pcseg_watershed4_f32": (c_int, [_P, c_int64, _P, _P, _P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_merge_groups_workspace_bytes": (c_size_t, [_I, _I]),
     "pcseg_merge_groups": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, c_size_t, _P]),

@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restric
     __shared__ unsigned sV[WS_N];
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
     if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
+    if (threadIdx.x == 0) atomicAdd(any_changed + 1, 1);  // tiles actually processed (measurement: bench.py roofline)
     const int r0 = ty * WS_T, c0 = tx * WS_T;
     const int64_t fbase = (int64_t)b * H * W;
     ws_load_tile(sL, L + fbase, r0, c0, H, W, WS_INF);
@@ -489,7 +490,17 @@ __global__ void __launch_bounds__(256) ws_exact_kernel(const unsigned *__restric
 
 using namespace pcseg;
 
+static long long g_ws_counters[4] = {0, 0, 0, 0};  // relax tiles processed, relax launches, calls, frames to exact path
+
 extern "C" {
+
+void pcseg_watershed_counters(int64_t *out, int reset)
+{
+    if (out)
+        for (int i = 0; i < 4; ++i) out[i] = g_ws_counters[i];
+    if (reset)
+        for (int i = 0; i < 4; ++i) g_ws_counters[i] = 0;
+}
 
 size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
 {
@@ -555,6 +566,8 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             }
         }
     };
+    PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int) * 16, s));
+    long long relax_launches = 0;
     PCSEG_LAUNCH(ws_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, frame_stride, markers, mask, val, L,
                        out, (int64_t)H * W, (int64_t)n);
     PCSEG_CHECK_LAUNCH();
@@ -564,6 +577,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     } else {
         int rc = iterate([&](uint8_t *din, uint8_t *dout) {
             PCSEG_LAUNCH(ws_relax_kernel, tgrid, dim3(256), 0, s, val, L, din, dout, changed, H, W, tilesX, tilesY);
+            ++relax_launches;
         });
         if (rc) return rc;
         const dim3 ugrid((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B);
@@ -633,7 +647,12 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         PCSEG_LAUNCH(ws_exact_kernel, dim3(B), dim3(256), 0, s, val, markers, mask, out, flags2, heap_key, heap_idx, H, W);
         PCSEG_CHECK_LAUNCH();
     }
+    int host_counts[2] = {0, 0};
+    PCSEG_CHECK_HIP(hipMemcpyAsync(host_counts, changed, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
     PCSEG_CHECK_HIP(hipStreamSynchronize(s));
+    g_ws_counters[0] += host_counts[1];
+    g_ws_counters[1] += relax_launches;
+    g_ws_counters[2] += 1;
     return PCSEG_OK;
 }
 

@@ -8,7 +8,7 @@ WRITE_SIZE are in KiB; FETCH_SIZE reads exactly half of the bytes of a wide coal
 (checked here on argmax_kernel: 5 planes x 64 frames x 4 MiB = 1.34 GB algorithmic vs 0.67 GB raw FETCH_SIZE);
 WRITE_SIZE is taken as is.  The two counters come from separate passes.
 
-    python profiles/summarize_rocprof.py gpurun_out/prof_r01 r01
+    python profiles/summarize_rocprof.py <dir with trace/ fetch/ write/> r01 [output dir]
 """
 import collections
 import csv
@@ -31,8 +31,9 @@ def short(name):
     return n
 
 
-def main(src, tag):
-    here = os.path.dirname(os.path.abspath(__file__))
+def main(src, tag, here=None):
+    here = here or os.path.dirname(os.path.abspath(__file__))
+    os.makedirs(here, exist_ok=True)
     trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
     dur = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
@@ -86,4 +87,4 @@ def main(src, tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
