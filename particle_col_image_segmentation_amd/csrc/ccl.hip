@@ -68,9 +68,15 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(KeyFn keyfn, int *__restr
         key[i] = (r < H && c < W) ? keyfn(b, r, c) : 0;
     }
     __syncthreads();
+    // row runs are pre-linked without atomics: a wave covers one 64-pixel tile row per trip (CCL_TW == 64), run heads
+    // come from a ballot and every pixel points straight at its run's first pixel (chains of length 1, not 64)
     for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
-        int k = key[i], lc = i % CCL_TW;
-        par[i] = k == 0 ? -1 : ((lc > 0 && key[i - 1] == k) ? i - 1 : i);
+        const int k = key[i], lc = i % CCL_TW;
+        const bool head = lc == 0 || key[i - 1] != k;
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long upto = heads & (lc == 63 ? ~0ull : ((2ull << lc) - 1ull));
+        const int start = 63 - __clzll((long long)upto);
+        par[i] = k == 0 ? -1 : (i - lc + start);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
