@@ -155,6 +155,12 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restric
     if (threadIdx.x == 0) *any_changed = 1;
 }
 
+// stage-2 work is restricted to the 64x64 tiles that hold a pixel of an unresolved component (active == nullptr: all)
+__device__ __forceinline__ bool ws_active(const uint8_t *active, int b, int r, int c, int tilesX, int tilesY)
+{
+    return active == nullptr || active[((int64_t)b * tilesY + r / WS_T) * tilesX + c / WS_T] != 0;
+}
+
 // (2) label assignment by union-find: every non-seed reachable pixel is united with ALL its
 // neighbours that hold the minimum neighbour key.  If no pixel has minimum-key neighbours in two basins (the proof
 // check's premise) the components are exactly the basins, each holding the seeds of one marker; a component that
@@ -163,15 +169,15 @@ constexpr int UF_TW = 64, UF_TH = 32, UF_SW = UF_TW + 2, UF_SH = UF_TH + 2;
 
 template <typename KeyT>
 __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const KeyT *__restrict__ K, const int *__restrict__ F,
-                                                          const int *__restrict__ frame_flags, int *__restrict__ parent,
-                                                          uint8_t *__restrict__ minmask, int H, int W)
+                                                          const uint8_t *__restrict__ active, int *__restrict__ parent,
+                                                          uint8_t *__restrict__ minmask, int H, int W, int tilesX, int tilesY)
 {
     __shared__ KeyT sK[UF_SH * UF_SW];
     __shared__ int par[UF_TH * UF_TW];
     const KeyT KINF = ~(KeyT)0;
     const int b = blockIdx.z;
-    if (frame_flags && frame_flags[b] == 0) return;
     const int r0 = blockIdx.y * UF_TH, c0 = blockIdx.x * UF_TW;
+    if (!ws_active(active, b, r0, c0, tilesX, tilesY)) return;  // UF tiles (64x32) nest inside the 64x64 tiles
     const int64_t fbase = (int64_t)b * H * W;
     for (int i = threadIdx.x; i < UF_SH * UF_SW; i += 256) {
         int r = r0 + i / UF_SW - 1, c = c0 + i % UF_SW - 1;
@@ -216,14 +222,14 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const KeyT *__restrict_
 }
 
 // cross-tile links from the neighbour masks the tile pass left behind
-__global__ void __launch_bounds__(256) ws_uf_border_kernel(const uint8_t *__restrict__ minmask, const int *__restrict__ frame_flags,
-                                                            int *__restrict__ parent, int H, int W)
+__global__ void __launch_bounds__(256) ws_uf_border_kernel(const uint8_t *__restrict__ minmask, const uint8_t *__restrict__ active,
+                                                            int *__restrict__ parent, int H, int W, int tilesX, int tilesY)
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (r >= H || c >= W) return;
     const int b = blockIdx.z;
-    if (frame_flags && frame_flags[b] == 0) return;
+    if (!ws_active(active, b, r, c, tilesX, tilesY)) return;
     const bool top = (r % UF_TH) == 0 && r > 0;
     const bool left = (c % UF_TW) == 0 && c > 0;
     if (!top && !left) return;
@@ -231,18 +237,20 @@ __global__ void __launch_bounds__(256) ws_uf_border_kernel(const uint8_t *__rest
     int *par = parent + fbase;
     const int p = r * W + c;
     const uint8_t mp = minmask[fbase + p];
-    if (top && ((mp & 1) || (minmask[fbase + p - W] & 8))) unite_glb(par, p, p - W);
-    if (left && ((mp & 2) || (minmask[fbase + p - 1] & 4))) unite_glb(par, p, p - 1);
+    if (top && ws_active(active, b, r - 1, c, tilesX, tilesY) && ((mp & 1) || (minmask[fbase + p - W] & 8)))
+        unite_glb(par, p, p - W);
+    if (left && ws_active(active, b, r, c - 1, tilesX, tilesY) && ((mp & 2) || (minmask[fbase + p - 1] & 4)))
+        unite_glb(par, p, p - 1);
 }
 
 // flatten + seeds publish their marker id at the root: hi = max id, nlo = max (INT_MAX - id)  (both start at 0)
 __global__ void __launch_bounds__(256) ws_uf_seed_kernel(int *__restrict__ parent, const int *__restrict__ F,
-                                                          const int *__restrict__ frame_flags, int *__restrict__ hi,
-                                                          int *__restrict__ nlo, int64_t n)
+                                                          const uint8_t *__restrict__ active, int *__restrict__ hi,
+                                                          int *__restrict__ nlo, int64_t n, int W, int tilesX, int tilesY)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
-    if (i >= n || (frame_flags && frame_flags[b] == 0)) return;
+    if (i >= n || !ws_active(active, b, (int)(i / W), (int)(i % W), tilesX, tilesY)) return;
     int *par = parent + (int64_t)b * n;
     int p = par[i];
     if (p < 0) return;
@@ -257,22 +265,30 @@ __global__ void __launch_bounds__(256) ws_uf_seed_kernel(int *__restrict__ paren
 }
 
 __global__ void __launch_bounds__(256) ws_uf_assign_kernel(const int *__restrict__ parent, int *__restrict__ F,
-                                                            const int *__restrict__ frame_flags, const int *__restrict__ hi,
-                                                            const int *__restrict__ nlo, int *__restrict__ tie_flags, int64_t n)
+                                                            const uint8_t *__restrict__ active, const int *__restrict__ hi,
+                                                            const int *__restrict__ nlo, int *__restrict__ tie_flags,
+                                                            uint8_t *__restrict__ mark_active, int64_t n, int W, int tilesX,
+                                                            int tilesY)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
-    if (i >= n || (frame_flags && frame_flags[b] == 0)) return;
+    const int r = (int)(i / W), c = (int)(i % W);
+    if (i >= n || !ws_active(active, b, r, c, tilesX, tilesY)) return;
     const int64_t g = (int64_t)b * n + i;
     int p = parent[g];
     if (p < 0) return;
-    // parents were flattened by the seed pass except where a later pixel re-pointed: one more hop is enough
     const int *par = parent + (int64_t)b * n;
     int x = p, q;
     while ((q = par[x]) != x) x = q;
     const int h = hi[(int64_t)b * n + x], l = 0x7FFFFFFF - nlo[(int64_t)b * n + x];
-    if (h != 0 && h != l && tie_flags[b] == 0) tie_flags[b] = 1;  // two markers in one component: not provable
-    if (F[g] == 0) F[g] = h;
+    const bool bad = h != 0 && h != l;  // two marker ids in one component: not provable at this level
+    if (bad) {
+        if (tie_flags[b] == 0) tie_flags[b] = 1;
+        // the next level only has to revisit the tiles that hold pixels of such components (every other component is
+        // already exactly the reference's basin: its pixels' minimum-key neighbours all lie inside it)
+        if (mark_active) mark_active[((int64_t)b * tilesY + r / WS_T) * tilesX + c / WS_T] = 1;
+    }
+    if (F[g] == 0 && !bad) F[g] = h;
 }
 
 // (3) proof check: every neighbour whose key equals the minimum neighbour key carries the pixel's label
@@ -316,14 +332,14 @@ constexpr unsigned WS_SECONDARY = 0xFFFFFFFEu;
 
 __global__ void __launch_bounds__(256) ws_k2_init_kernel(const unsigned *__restrict__ val, const unsigned *__restrict__ L,
                                                           const int *__restrict__ markers, const uint8_t *__restrict__ mask,
-                                                          const int *__restrict__ frame_flags, unsigned *__restrict__ K2,
-                                                          int H, int W)
+                                                          const uint8_t *__restrict__ active, unsigned *__restrict__ K2,
+                                                          int H, int W, int tilesX, int tilesY)
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (r >= H || c >= W) return;
     const int b = blockIdx.z;
-    if (frame_flags[b] == 0) return;
+    if (!ws_active(active, b, r, c, tilesX, tilesY)) return;
     const int64_t i = (int64_t)b * H * W + (int64_t)r * W + c;
     const unsigned l = L[i];
     unsigned k = WS_INF;
@@ -340,7 +356,7 @@ __global__ void __launch_bounds__(256) ws_k2_init_kernel(const unsigned *__restr
 }
 
 __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const unsigned *__restrict__ val, const unsigned *__restrict__ L,
-                                                           unsigned *__restrict__ K2, const int *__restrict__ frame_flags,
+                                                           unsigned *__restrict__ K2, const uint8_t *__restrict__ active,
                                                            const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
                                                            int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
 {
@@ -348,7 +364,7 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const unsigned *__rest
     __shared__ unsigned sK[WS_N];
     __shared__ uint8_t sLake[WS_N];
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
-    if (frame_flags[b] == 0) return;
+    if (!active[((int64_t)b * tilesY + ty) * tilesX + tx]) return;  // K2 is only defined inside the active tiles
     if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
     const int r0 = ty * WS_T, c0 = tx * WS_T;
     const int64_t fbase = (int64_t)b * H * W;
@@ -386,17 +402,38 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const unsigned *__rest
     if (threadIdx.x == 0) *any_changed = 1;
 }
 
-// K64 = (L << 32) | K2 and reset of the labels to the seeds, flagged frames only
-__global__ void __launch_bounds__(256) ws_pack_reset_kernel(const unsigned *__restrict__ L, const unsigned *__restrict__ K2,
-                                                             const int *__restrict__ markers, const uint8_t *__restrict__ mask,
-                                                             const int *__restrict__ frame_flags,
-                                                             unsigned long long *__restrict__ K64, int *__restrict__ out,
-                                                             int64_t n, int64_t total)
+// K64 = (L << 32) | K2 inside the active tiles (and the union-find root slots are cleared there); every other pixel of
+// a flagged frame gets (L, worst K2): it can sit in the halo of an active tile, where it must never look like a
+// minimum-key neighbour (it is not in the component, so its L is larger than the minimum anyway)
+__global__ void __launch_bounds__(256) ws_pack_kernel(const unsigned *__restrict__ L, const unsigned *__restrict__ K2,
+                                                       const int *__restrict__ frame_flags, const uint8_t *__restrict__ active,
+                                                       unsigned long long *__restrict__ K64, int *__restrict__ hi,
+                                                       int *__restrict__ nlo, int64_t n, int W, int tilesX, int tilesY)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total || frame_flags[i / n] == 0) return;
-    K64[i] = ((unsigned long long)L[i] << 32) | K2[i];
-    out[i] = mask[i] ? markers[i] : 0;
+    const int b = blockIdx.y;
+    if (i >= n || frame_flags[b] == 0) return;
+    const int64_t g = (int64_t)b * n + i;
+    if (ws_active(active, b, (int)(i / W), (int)(i % W), tilesX, tilesY)) {
+        K64[g] = ((unsigned long long)L[g] << 32) | K2[g];
+        hi[g] = 0;
+        nlo[g] = 0;
+    } else {
+        K64[g] = ((unsigned long long)L[g] << 32) | 0xFFFFFFFFull;
+    }
+}
+
+// verification builds of the second level run on whole flagged frames: every tile of such a frame becomes active and
+// its labels are reset to the seeds
+__global__ void __launch_bounds__(256) ws_activate_frames_kernel(const int *__restrict__ frame_flags, uint8_t *__restrict__ active,
+                                                                  const int *__restrict__ markers, const uint8_t *__restrict__ mask,
+                                                                  int *__restrict__ out, int64_t n, int W, int tilesX, int tilesY)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= n || frame_flags[b] == 0) return;
+    active[((int64_t)b * tilesY + (int)(i / W) / WS_T) * tilesX + (int)(i % W) / WS_T] = 1;
+    out[(int64_t)b * n + i] = mask[(int64_t)b * n + i] ? markers[(int64_t)b * n + i] : 0;
 }
 
 __global__ void ws_set_flags_kernel(int *flags, int B, int v)
@@ -507,7 +544,7 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
     if (!check_shape(B, H, W)) return 0;
     size_t n = (size_t)B * H * W;
     int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
-    return 5 * align_up(n * 4) + align_up(n) + 2 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + 2 * align_up(sizeof(int) * B) +
+    return 5 * align_up(n * 4) + align_up(n) + 3 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + 2 * align_up(sizeof(int) * B) +
            align_up(n * 8) + align_up(n * 4);
 }
 
@@ -529,6 +566,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     unsigned *L = cv.take<unsigned>(n);
     uint8_t *dirtyA = cv.take<uint8_t>(ntiles);
     uint8_t *dirtyB = cv.take<uint8_t>(ntiles);
+    uint8_t *active_tiles = cv.take<uint8_t>(ntiles);
     int *changed = cv.take<int>(16);
     int *flags = cv.take<int>(B);
     int *flags2 = cv.take<int>(B);
@@ -544,9 +582,11 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     }
     const dim3 tgrid(tilesX, tilesY, B);
     const dim3 pgrid((W + 63) / 64, (H + 3) / 4, B);
-    // host-driven fixed point: `launch(din, dout)` enqueues one round; polled every 4 rounds
-    auto iterate = [&](auto &&launch) -> int {
-        PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 1, ntiles, s));
+    // host-driven fixed point: `launch(din, dout)` enqueues one round; polled every 4 rounds.  `first` = tiles that
+    // start dirty (nullptr: all)
+    auto iterate = [&](const uint8_t *first, auto &&launch) -> int {
+        if (first) PCSEG_CHECK_HIP(hipMemcpyAsync(dirtyA, first, ntiles, hipMemcpyDeviceToDevice, s));
+        else PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 1, ntiles, s));
         uint8_t *din = dirtyA, *dout = dirtyB;
         for (int round = 0;; round += 4) {
             PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int), s));
@@ -575,34 +615,39 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         PCSEG_LAUNCH(ws_set_flags_kernel, dim3((B + 63) / 64), dim3(64), 0, s, flags2, B, 1);
         PCSEG_CHECK_LAUNCH();
     } else {
-        int rc = iterate([&](uint8_t *din, uint8_t *dout) {
+        int rc = iterate(nullptr, [&](uint8_t *din, uint8_t *dout) {
             PCSEG_LAUNCH(ws_relax_kernel, tgrid, dim3(256), 0, s, val, L, din, dout, changed, H, W, tilesX, tilesY);
             ++relax_launches;
         });
         if (rc) return rc;
         const dim3 ugrid((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B);
         const dim3 lgrid((unsigned)(((size_t)H * W + 255) / 256), B);
-        // label assignment = union-find over "minimum-key neighbour" links (flags the frame on a two-marker component)
-        auto assign_labels = [&](auto *keys, const int *frame_flags, int *out_flags) -> int {
+        const int64_t npx = (int64_t)H * W;
+        // label assignment = union-find over "minimum-key neighbour" links.  A component holding two marker ids flags
+        // its frame, stays unlabelled and (first level) marks its tiles active for the next level.
+        auto assign_labels = [&](auto *keys, const uint8_t *act, int *out_flags, uint8_t *mark) -> int {
             using KeyT = std::remove_const_t<std::remove_pointer_t<decltype(keys)>>;
-            PCSEG_CHECK_HIP(hipMemsetAsync(uf_hi, 0, sizeof(int) * n, s));
-            PCSEG_CHECK_HIP(hipMemsetAsync(uf_nlo, 0, sizeof(int) * n, s));
-            PCSEG_LAUNCH(ws_uf_tile_kernel<KeyT>, ugrid, dim3(256), 0, s, (const KeyT *)keys, (const int *)out, frame_flags,
-                         uf_parent, uf_mask, H, W);
+            PCSEG_LAUNCH(ws_uf_tile_kernel<KeyT>, ugrid, dim3(256), 0, s, (const KeyT *)keys, (const int *)out, act, uf_parent,
+                         uf_mask, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            PCSEG_LAUNCH(ws_uf_border_kernel, pgrid, dim3(256), 0, s, (const uint8_t *)uf_mask, frame_flags, uf_parent, H, W);
+            PCSEG_LAUNCH(ws_uf_border_kernel, pgrid, dim3(256), 0, s, (const uint8_t *)uf_mask, act, uf_parent, H, W, tilesX,
+                         tilesY);
             PCSEG_CHECK_LAUNCH();
-            PCSEG_LAUNCH(ws_uf_seed_kernel, lgrid, dim3(256), 0, s, uf_parent, (const int *)out, frame_flags, uf_hi, uf_nlo,
-                         (int64_t)H * W);
+            PCSEG_LAUNCH(ws_uf_seed_kernel, lgrid, dim3(256), 0, s, uf_parent, (const int *)out, act, uf_hi, uf_nlo, npx, W,
+                         tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            PCSEG_LAUNCH(ws_uf_assign_kernel, lgrid, dim3(256), 0, s, (const int *)uf_parent, out, frame_flags,
-                         (const int *)uf_hi, (const int *)uf_nlo, out_flags, (int64_t)H * W);
+            PCSEG_LAUNCH(ws_uf_assign_kernel, lgrid, dim3(256), 0, s, (const int *)uf_parent, out, act, (const int *)uf_hi,
+                         (const int *)uf_nlo, out_flags, mark, npx, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
             return PCSEG_OK;
         };
+        uint8_t *active = dirtyB;  // free between the fixed-point loops: which tiles the second level has to revisit
         PCSEG_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * B, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(flags2, 0, sizeof(int) * B, s));
-        rc = assign_labels((const unsigned *)L, (const int *)nullptr, flags);
+        PCSEG_CHECK_HIP(hipMemsetAsync(active, 0, ntiles, s));
+        PCSEG_CHECK_HIP(hipMemsetAsync(uf_hi, 0, sizeof(int) * n, s));
+        PCSEG_CHECK_HIP(hipMemsetAsync(uf_nlo, 0, sizeof(int) * n, s));
+        rc = assign_labels((const unsigned *)L, (const uint8_t *)nullptr, flags, active);
         if (rc) return rc;
         if (verify) {
             PCSEG_LAUNCH(ws_check_kernel<unsigned>, pgrid, dim3(256), 0, s, (const unsigned *)L, (const int *)out, markers, mask,
@@ -622,18 +667,26 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         if (any_flag) {
             unsigned *K2 = heap_idx;
             unsigned long long *K64 = heap_key;
+            if (verify) {
+                // whole flagged frames, so that the explicit per-pixel check of the second level sees valid keys everywhere
+                PCSEG_LAUNCH(ws_activate_frames_kernel, lgrid, dim3(256), 0, s, (const int *)flags, active, markers, mask, out,
+                             npx, W, tilesX, tilesY);
+                PCSEG_CHECK_LAUNCH();
+            }
+            // the fixed-point loop below reuses dirtyB: keep the active set in its own buffer
+            PCSEG_CHECK_HIP(hipMemcpyAsync(active_tiles, active, ntiles, hipMemcpyDeviceToDevice, s));
             PCSEG_LAUNCH(ws_k2_init_kernel, pgrid, dim3(256), 0, s, (const unsigned *)val, (const unsigned *)L, markers, mask,
-                         (const int *)flags, K2, H, W);
+                         (const uint8_t *)active_tiles, K2, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            rc = iterate([&](uint8_t *din, uint8_t *dout) {
+            rc = iterate(active_tiles, [&](uint8_t *din, uint8_t *dout) {
                 PCSEG_LAUNCH(ws_k2_relax_kernel, tgrid, dim3(256), 0, s, (const unsigned *)val, (const unsigned *)L, K2,
-                             (const int *)flags, din, dout, changed, H, W, tilesX, tilesY);
+                             (const uint8_t *)active_tiles, din, dout, changed, H, W, tilesX, tilesY);
             });
             if (rc) return rc;
-            PCSEG_LAUNCH(ws_pack_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned *)L,
-                         (const unsigned *)K2, markers, mask, (const int *)flags, K64, out, (int64_t)H * W, (int64_t)n);
+            PCSEG_LAUNCH(ws_pack_kernel, lgrid, dim3(256), 0, s, (const unsigned *)L, (const unsigned *)K2, (const int *)flags,
+                         (const uint8_t *)active_tiles, K64, uf_hi, uf_nlo, npx, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            rc = assign_labels((const unsigned long long *)K64, (const int *)flags, flags2);
+            rc = assign_labels((const unsigned long long *)K64, (const uint8_t *)active_tiles, flags2, (uint8_t *)nullptr);
             if (rc) return rc;
             if (verify) {
                 PCSEG_LAUNCH(ws_check_kernel<unsigned long long>, pgrid, dim3(256), 0, s, (const unsigned long long *)K64,
