@@ -41,7 +41,7 @@ class BatchResult(dict):
 
 class FramePipeline:
     def __init__(self, cell_types=None, threshold=0.5, boundary_plane=BOUNDARY_PLANE, cap=None, merged=True,
-                 watershed_mode=0):
+                 watershed_mode=0, overlap=True):
         self.cell_types = dict(cell_types or CELL_TYPES_5)
         self.tables_ = ops.ClassTables(self.cell_types, ta.CELL_TYPES, ta.MIN_CELL_AREA, ta.MIN_CLUSTER_AREA)
         self.threshold = float(threshold)
@@ -49,15 +49,40 @@ class FramePipeline:
         self.cap = cap
         self.merged = merged
         self.watershed_mode = watershed_mode
+        self.overlap = overlap
+        self._streams = None
 
     def run(self, stack):
         if stack.dim() != 4 or stack.dtype != torch.float32 or not stack.is_cuda:
             raise TypeError("stack must be a (B, C, H, W) float32 CUDA tensor")
         stack = stack.contiguous()
+        res = BatchResult()
+        res["shape"] = tuple(stack.shape)
+        if not self.overlap:
+            self._class_chain(stack, res)
+            self._refine_chain(stack, res)
+            return res
+        # The class-map chain and the boundary-refinement chain only share the input.  The first is enqueued
+        # asynchronously on its own HIP stream; the second (whose relaxation polls the host) then runs on another, so
+        # the many short launches and polls of the watershed's late rounds overlap with the first chain's kernels.
+        cur = torch.cuda.current_stream()
+        if self._streams is None or self._streams[0].device != stack.device:
+            self._streams = (torch.cuda.Stream(device=stack.device), torch.cuda.Stream(device=stack.device))
+        s1, s2 = self._streams
+        s1.wait_stream(cur)
+        s2.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            self._class_chain(stack, res)
+        with torch.cuda.stream(s2):
+            self._refine_chain(stack, res)
+        s1.synchronize()
+        s2.synchronize()
+        return res
+
+    def _class_chain(self, stack, res):
         B, C, H, W = stack.shape
         cap = self.cap or max(1024, (H * W) // 64)
         tb = self.tables_
-        res = BatchResult()
         # ---- class map + denoise (A1)
         cls = ops.argmax_planes(stack)
         z = ops.median5(cls)
@@ -98,6 +123,10 @@ class FramePipeline:
                                                 ta.DISTANCE_THRESHOLD, overlap)
         res["recreated"] = ds
         res["overlap_area"] = overlap
+
+    def _refine_chain(self, stack, res):
+        B, C, H, W = stack.shape
+        cap = self.cap or max(1024, (H * W) // 64)
         # ---- boundary refinement (R1-R4, W1) on the boundary plane, read in place
         bm = stack[:, self.boundary_plane]
         d2, mask = ops.edt_sq_lt(bm, self.threshold)
@@ -107,8 +136,6 @@ class FramePipeline:
         # ---- isotope sums of the refined ROIs (M1)
         ws_stats, _, ws_sums, ws_overflow = ops.region_reduce(ws_labels, n_markers, planes=stack, cap=cap)
         res.update(ws_stats=ws_stats, ws_sums=ws_sums, ws_overflow=ws_overflow)
-        res["shape"] = (B, C, H, W)
-        return res
 
     # ------------------------------------------------------------------ host epilogue
     def tables(self, res, frame_ids=None, ratios=RATIOS_5, distances=False, raster=19.0):
