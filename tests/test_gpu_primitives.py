@@ -324,3 +324,40 @@ def test_extensions_otsu_morph(ops):
     thr = ops.threshold_otsu(dev(img))
     for i in range(2):
         assert abs(thr[i] - orc.threshold_otsu(img[i])[0]) < 1e-12
+
+
+def test_watershed_proof_holds_on_adversarial_ties(ops):
+    """Property behind the parallel path: whenever it reports a frame as proven (tie flag 0, mode 2 = no exact
+    fallback) the labels equal the reference's sequential flood -- on images built to be full of ties, plateaus, lakes
+    and equal-valued seeds.  Batches of frames so that flagged and proven frames mix inside one launch."""
+    rng = np.random.default_rng(2024)
+    proven = flagged = 0
+    for (B, H, W, levels, pm, pk) in [(48, 24, 31, 3, 0.9, 0.03), (48, 33, 33, 6, 1.0, 0.02), (32, 40, 70, 12, 0.8, 0.01),
+                                      (32, 64, 64, 50, 0.95, 0.004), (24, 70, 130, 0, 0.9, 0.003), (16, 96, 96, 200, 1.0, 0.002)]:
+        img = rng.random((B, H, W)).astype(np.float32)
+        if levels:
+            img = (np.floor(img * levels) / levels).astype(np.float32)
+        # smooth a little so that lakes (pits without seeds) exist at every level
+        img = ((img + np.roll(img, 1, 1) + np.roll(img, 1, 2)) / 3).astype(np.float32) if levels != 3 else img
+        mask = rng.random((B, H, W)) < pm
+        mk = np.zeros((B, H, W), np.int32)
+        for b in range(B):
+            sel = rng.random((H, W)) < pk
+            mk[b][sel] = rng.permutation(int(sel.sum())).astype(np.int32) + 1
+            if b % 3 == 0:
+                mk[b, 1:3, 1:4] = 500  # a multi-pixel marker
+        out, flags = ops.watershed(dev(img), dev(mk), dev(mask), mode=2)
+        out_v, flags_v = ops.watershed(dev(img), dev(mk), dev(mask), mode=6)
+        full, _ = ops.watershed(dev(img), dev(mk), dev(mask), mode=0)
+        out, flags, out_v, flags_v, full = host(out), host(flags), host(out_v), host(flags_v), host(full)
+        np.testing.assert_array_equal(flags, flags_v)  # component test == explicit per-pixel proof check
+        for b in range(B):
+            exp = orc.watershed(img[b], mk[b], mask[b])
+            np.testing.assert_array_equal(full[b], exp)
+            if flags[b] == 0:
+                np.testing.assert_array_equal(out[b], exp)
+                np.testing.assert_array_equal(out_v[b], exp)
+                proven += 1
+            else:
+                flagged += 1
+    assert proven > 20 and flagged > 20, (proven, flagged)
