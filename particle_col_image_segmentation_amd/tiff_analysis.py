@@ -358,67 +358,66 @@ def combine_cell_positions_and_clusters(dapi_channel, other_channel):
 
 
 def get_rfp_base_arr(rfp_arr, cell_strains):
-    """tiff_analysis.py:224-231 (in-place class remap)."""
-    if cell_strains == ["6B07"] or cell_strains == ["6B07", "C3M10"]:
-        rfp_arr[rfp_arr == 1] = 4
-        rfp_arr[rfp_arr == 2] = 5
-    else:
-        rfp_arr[rfp_arr == 2] = 4
-        rfp_arr[rfp_arr == 3] = 5
+    """Lift a per-channel RFP class map into the 5-class numbering, in place (tiff_analysis.py:224-231): without a
+    3D05 strain the RFP channel holds (particle, background) = (1, 2), otherwise (cell, particle, background)."""
+    particle, background = (1, 2) if cell_strains in (["6B07"], ["6B07", "C3M10"]) else (2, 3)
+    rfp_arr[rfp_arr == particle] = 4   # order matters: the particle value is remapped before the background value
+    rfp_arr[rfp_arr == background] = 5
     return rfp_arr
 
 
 def combine_channels(rfp_base, channel_ds_arrs, cell_strains):
-    """tiff_analysis.py:233-249."""
+    """Paint the cells of every non-3D05 strain (value 1 of its own channel) into the RFP base map with the strain's
+    value of BASE_TYPE_MAP (tiff_analysis.py:233-249)."""
+    value_of = {name: val for val, name in BASE_TYPE_MAP.items()}
     for strain in cell_strains:
-        if strain == "3D05":
-            continue
-        channel_name = STRAIN_MAP[strain]
-        for val, strain_name in BASE_TYPE_MAP.items():
-            if strain_name == strain:
-                rfp_base[channel_ds_arrs[channel_name] == 1] = val
+        if strain != "3D05":
+            rfp_base[channel_ds_arrs[STRAIN_MAP[strain]] == 1] = value_of[strain]
     return rfp_base
 
 
 def normalize_ds_arr(ds_arr):
-    """tiff_analysis.py:727-737."""
-    if ds_arr.shape[-1] == 1:
+    """Squeeze an ilastik export to (H, W) (tiff_analysis.py:727-737): (H, W, 1), (1, H, W) or exactly 2048 x 2048."""
+    shape = ds_arr.shape
+    if shape[-1] == 1:
         return np.squeeze(ds_arr)
-    elif ds_arr.shape[0] == 1:
+    if shape[0] == 1:
         return ds_arr[0]
-    elif ds_arr.shape[0] == 2048 and ds_arr.shape[1] == 2048:
+    if shape[0] == 2048 and shape[1] == 2048:
         return ds_arr
-    else:
-        raise ValueError(f"DS arr shape is not (2048,2048,1) or (1,2048,2048) or (2048,2048). Shape: {ds_arr.shape}")
+    raise ValueError(f"DS arr shape is not (2048,2048,1) or (1,2048,2048) or (2048,2048). Shape: {ds_arr.shape}")
 
 
 def get_strains_from_file(file_name):
-    """tiff_analysis.py:673-678."""
-    return [cell_type for cell_type in CELL_TYPES if cell_type in file_name.upper()]
+    """Strain names (in CELL_TYPES order) that occur in the upper-cased path (tiff_analysis.py:673-678)."""
+    upper = file_name.upper()
+    return [strain for strain in CELL_TYPES if strain in upper]
 
 
 def get_channel_from_file(file_name):
-    """tiff_analysis.py:680-687."""
-    channels = [channel for channel in CHANNELS if channel in file_name.upper()]
-    if len(channels) > 1:
+    """The one fluorescence channel named in the file (tiff_analysis.py:680-687); IndexError without any."""
+    upper = file_name.upper()
+    found = [channel for channel in CHANNELS if channel in upper]
+    if len(found) > 1:
         raise ValueError("More than one channel found in file path")
-    return channels[0]
+    return found[0]
 
 
 def get_cell_type_map(file_path):
-    """tiff_analysis.py:694-702."""
-    cell_types = get_strains_from_file(file_path)
-    cell_type_map = {}
-    for i, cell_type in enumerate(cell_types):
-        cell_type_map[i + 1] = cell_type
-    cell_type_map[i + 2] = "Particle"  # UnboundLocalError without any strain in the name, like the reference
-    cell_type_map[i + 3] = "Background"
+    """{1..k: strains named in the file, k+1: "Particle", k+2: "Background"} (tiff_analysis.py:694-702).  Like the
+    reference this needs at least one strain in the name (UnboundLocalError otherwise)."""
+    strains = get_strains_from_file(file_path)
+    if not strains:
+        raise UnboundLocalError("local variable 'i' referenced before assignment")
+    cell_type_map = dict(enumerate(strains, start=1))
+    cell_type_map[len(strains) + 1] = "Particle"
+    cell_type_map[len(strains) + 2] = "Background"
     return cell_type_map
 
 
 def get_cell_type_map_from_channel(strain_types, channel):
-    """tiff_analysis.py:709-712."""
-    if (strain_types == ["6B07"] and channel == "RFP") or (strain_types == ["6B07", "C3M10"] and channel == "RFP"):
+    """Class values of one channel file of a multi-channel sample (tiff_analysis.py:709-712)."""
+    if channel == "RFP" and strain_types in (["6B07"], ["6B07", "C3M10"]):
         return {1: "Particle", 2: "Background"}
     return {1: CHANNEL_MAP[channel], 2: "Particle", 3: "Background"}
 
@@ -432,68 +431,71 @@ def get_pos_and_density_file_names(cur_folder):
     return density_info_file_path, cell_pos_file_name
 
 
-def write_cell_position_info(cell_positions, cell_clusters, csv_output_file, particle_area):
-    """tiff_analysis.py:1047-1063 (csv.writer default dialect, file opened without newline='')."""
-    particle_area = particle_area / (PX_TO_UM_CONV ** 2)
+def _um2(area_px):
+    """pixels^2 -> micrometres^2 with the reference's conversion factor (PX_TO_UM_CONV, tiff_analysis.py:82)."""
+    return area_px / (PX_TO_UM_CONV ** 2)
+
+
+def _write_rows(csv_output_file, header, rows):
+    # csv.writer's default dialect on a file opened without newline="" -- the reference's output has \r\n line ends
     with open(csv_output_file, "w") as f:
-        writer = csv.writer(f)
-        writer.writerow(["strain", "cell_type", "x_pos", "y_pos", "cell_area", "cell_area_ratio", "cell_count"])
-        for strain_type, pos in cell_positions.items():
-            for p in pos:
-                cell_pos = p.centroid
-                area = p.area / (PX_TO_UM_CONV ** 2)
-                area_ratio = area / particle_area
-                writer.writerow([strain_type, "cell", round(cell_pos[1], 2), round(cell_pos[0], 2), round(area, 5),
-                                 round(area_ratio, 8), 1])
-        for strain_type, cluster in cell_clusters.items():
-            for c in cluster:
-                pos = c.centroid
-                area = c.area / (PX_TO_UM_CONV ** 2)
-                area_ratio = area / particle_area
-                writer.writerow([strain_type, "cluster", round(pos[1], 2), round(pos[0], 2), area, round(area_ratio, 8), c.cells])
+        out = csv.writer(f)
+        out.writerow(header)
+        out.writerows(rows)
+
+
+def write_cell_position_info(cell_positions, cell_clusters, csv_output_file, particle_area):
+    """``<folder>_cell_pos.csv`` (tiff_analysis.py:1047-1063): one row per single cell (area rounded to 5 decimals,
+    count 1) then one per cluster (area left unrounded, count = cluster.cells); x = column, y = row, 2 decimals."""
+    particle_um2 = _um2(particle_area)
+
+    def rows():
+        for kind, table in (("cell", cell_positions), ("cluster", cell_clusters)):
+            for strain_type, regions in table.items():
+                for region in regions:
+                    row_pos, col_pos = region.centroid
+                    area = _um2(region.area)
+                    shown_area = round(area, 5) if kind == "cell" else area
+                    count = 1 if kind == "cell" else region.cells
+                    yield [strain_type, kind, round(col_pos, 2), round(row_pos, 2), shown_area,
+                           round(area / particle_um2, 8), count]
+
+    _write_rows(csv_output_file, ["strain", "cell_type", "x_pos", "y_pos", "cell_area", "cell_area_ratio", "cell_count"],
+                rows())
 
 
 def write_merged_cell_position_info(merged_clusters, csv_output_file, particle_area):
-    """tiff_analysis.py:1065-1075."""
-    particle_area = particle_area / (PX_TO_UM_CONV ** 2)
-    with open(csv_output_file, "w") as f:
-        writer = csv.writer(f)
-        writer.writerow(["strain_type", "x_pos", "y_pos", "cell_area", "cell_area_ratio", "cell_num"])
-        for strain_type, pos in merged_clusters.items():
-            for p in pos:
-                cell_pos = p["centroid"]
-                area = p["area"] / (PX_TO_UM_CONV ** 2)
-                area_ratio = area / particle_area
-                writer.writerow([strain_type, round(cell_pos[1], 2), round(cell_pos[0], 2), round(area, 5),
-                                 round(area_ratio, 8), len(p["regions"])])
+    """``<folder>_merged_cell_pos.csv`` (tiff_analysis.py:1065-1075): one row per merged group."""
+    particle_um2 = _um2(particle_area)
+
+    def rows():
+        for strain_type, groups in merged_clusters.items():
+            for group in groups:
+                row_pos, col_pos = group["centroid"]
+                area = _um2(group["area"])
+                yield [strain_type, round(col_pos, 2), round(row_pos, 2), round(area, 5), round(area / particle_um2, 8),
+                       len(group["regions"])]
+
+    _write_rows(csv_output_file, ["strain_type", "x_pos", "y_pos", "cell_area", "cell_area_ratio", "cell_num"], rows())
 
 
 def write_density_info(csv_output_file, h5_folder, cell_density, cell_area_ratio, cell_count):
-    """tiff_analysis.py:1078-1107: rows of the same folder are replaced, others kept."""
+    """Per-parent-folder density summary (tiff_analysis.py:1078-1107): rows of ``h5_folder`` already in the file are
+    dropped (the file is rewritten without them), then this run's rows are appended -- reruns stay idempotent."""
     header = ["folder", "strain", "cell_density", "cell_area_ratio", "cell_count"]
-    existing_data = []
-    path_exists = os.path.exists(csv_output_file)
-    data_exists = False
-    if path_exists:
+    is_new = not os.path.exists(csv_output_file)
+    if not is_new:
         with open(csv_output_file, "r") as f:
-            reader = csv.reader(f)
-            next(reader)
-            for row in reader:
-                if row[0] == h5_folder:
-                    data_exists = True
-                else:
-                    existing_data.append(row)
-    if data_exists:
-        with open(csv_output_file, "w") as f:
-            writer = csv.writer(f)
-            writer.writerow(header)
-            writer.writerows(existing_data)
+            old_rows = list(csv.reader(f))[1:]
+        kept = [row for row in old_rows if row[0] != h5_folder]
+        if len(kept) != len(old_rows):
+            _write_rows(csv_output_file, header, kept)
     with open(csv_output_file, "a") as f:
-        writer = csv.writer(f)
-        if not path_exists:
-            writer.writerow(header)
-        for strain in cell_density:
-            writer.writerow([h5_folder, strain, cell_density[strain], cell_area_ratio[strain], cell_count[strain]])
+        out = csv.writer(f)
+        if is_new:
+            out.writerow(header)
+        out.writerows([h5_folder, strain, cell_density[strain], cell_area_ratio[strain], cell_count[strain]]
+                      for strain in cell_density)
 
 
 def read_class_map(path):
@@ -529,61 +531,64 @@ def process_single_h5_file(cur_folder, file_path):
     write_density_info(density_info_file_path, processed_folder, cell_density, cell_area_ratio, cell_count)
 
 
+def _analyse_channel_file(cur_folder, file, cell_strains):
+    """One channel file of a multi-channel sample (loop body of tiff_analysis.py:107-157, no figures)."""
+    channel = get_channel_from_file(file)
+    cell_types = get_cell_type_map_from_channel(cell_strains, channel)
+    denoised = median_filter(normalize_ds_arr(read_class_map(os.path.join(cur_folder, file))), size=DENOISE_SIZE)
+    positions, clusters, particle_area, _ = get_cell_positions_and_areas(denoised, cell_types)
+    return channel, cell_types, denoised, positions, clusters, particle_area
+
+
 def process_multiple_h5_files(cur_folder, h5_files):
-    """tiff_analysis.py:92-222 without the matplotlib figures: per-channel class maps of one sample (DAPI / RFP / GFP),
-    DAPI cells that overlap the other channel removed (:167), channels recombined (:202-204), merged clusters of the
-    combined map (:206); writes *_cell_pos_raw.csv, *_cell_pos_combined.csv, *_merged_cell_pos.csv and the density CSV."""
-    density_info_file_path, cell_pos_file_name = get_pos_and_density_file_names(cur_folder)
-    cell_pos_raw_file_name = cell_pos_file_name.replace("_cell_pos.csv", "_cell_pos_raw.csv")
-    cell_pos_combined_file_name = cell_pos_file_name.replace("_cell_pos.csv", "_cell_pos_combined.csv")
-    processed_folder = cur_folder.split("/")[-1]
-    rfp_particle_area = None
-    master_cell_pos = {}
-    master_cell_clusters = {}
-    channel_ds_arrs = {}
-    dapi_cell_types = None
+    """A sample exported as one class map per fluorescence channel (tiff_analysis.py:92-222), without the figures.
+
+    Per file: denoise + region table; the RFP file also yields the (recreated) particle area every density refers to.
+    Then the raw position CSV, DAPI cells that overlap the other channel by more than 10 % removed (:167-170), densities,
+    the channels recombined into one 5-class map (:198-204) whose merged clusters go to ``*_merged_cell_pos.csv``.
+    Returns (combined class map, merged clusters)."""
+    density_csv, cell_pos_csv = get_pos_and_density_file_names(cur_folder)
+    raw_csv = cell_pos_csv.replace("_cell_pos.csv", "_cell_pos_raw.csv")
+    combined_csv = cell_pos_csv.replace("_cell_pos.csv", "_cell_pos_combined.csv")
+    merged_csv = combined_csv.replace("_cell_pos_combined.csv", "_merged_cell_pos.csv")
+    sample_name = cur_folder.split("/")[-1]
     cell_strains = get_strains_from_file(cur_folder)
+
+    all_positions, all_clusters, denoised_by_channel = {}, {}, {}
+    rfp_particle_area, dapi_cell_types = None, None
     for file in h5_files:
-        full_file_path = os.path.join(cur_folder, file)
-        channel = get_channel_from_file(file)
-        cell_types = get_cell_type_map_from_channel(cell_strains, channel)
-        strain_type = cell_types[1]
-        if len(cell_types) == 0:
-            raise ValueError("Cell type not found in file path")
-        ds_arr = normalize_ds_arr(read_class_map(full_file_path))
-        ds_arr_denoised = median_filter(ds_arr, size=DENOISE_SIZE)
-        cell_positions, cell_clusters, particle_area, _ = get_cell_positions_and_areas(ds_arr_denoised, cell_types)
-        channel_ds_arrs[channel] = ds_arr_denoised
+        channel, cell_types, denoised, positions, clusters, particle_area = _analyse_channel_file(cur_folder, file, cell_strains)
+        denoised_by_channel[channel] = denoised
+        first_type = cell_types[1]
         if channel == "RFP":
-            rfp_particle_area = particle_area
-            _, rfp_particle_area = recreate_particle_area(ds_arr_denoised, cell_types, particle_area)
-            if strain_type == "Particle":
+            _, rfp_particle_area = recreate_particle_area(denoised, cell_types, particle_area)
+            if first_type == "Particle":  # an RFP channel that only shows the particle carries no cells (:131-132)
                 continue
         elif channel == "DAPI":
             dapi_cell_types = cell_types
-        if strain_type not in CELL_TYPES:
-            raise ValueError(f"Strain type not in cell types. {strain_type}")
-        master_cell_pos.update(cell_positions)
-        master_cell_clusters.update(cell_clusters)
+        if first_type not in CELL_TYPES:
+            raise ValueError(f"Strain type not in cell types. {first_type}")
+        all_positions.update(positions)
+        all_clusters.update(clusters)
     if rfp_particle_area is None:
         raise ValueError("RFP particle area not found")
-    write_cell_position_info(master_cell_pos, master_cell_clusters, cell_pos_raw_file_name, rfp_particle_area)
+    write_cell_position_info(all_positions, all_clusters, raw_csv, rfp_particle_area)
+
     if len(cell_strains) > 1:
-        other_channel = channel_ds_arrs["GFP"] if cell_strains == ["6B07", "C3M10"] else channel_ds_arrs["RFP"]
-        dapi_updated = combine_cell_positions_and_clusters(channel_ds_arrs["DAPI"], other_channel)
-        dapi_cell_positions, dapi_cell_clusters, _, _ = get_cell_positions_and_areas(dapi_updated, dapi_cell_types)
-        master_cell_pos["6B07"] = dapi_cell_positions["6B07"]
-        master_cell_clusters["6B07"] = dapi_cell_clusters["6B07"]
-    cell_counts, cell_densities, cell_area_ratios = get_cell_counts_and_densities(
-        master_cell_pos, master_cell_clusters, rfp_particle_area)
-    write_density_info(density_info_file_path, processed_folder, cell_densities, cell_area_ratios, cell_counts)
-    rfp_base_arr = channel_ds_arrs["RFP"].copy()
-    get_rfp_base_arr(rfp_base_arr, cell_strains)
-    combined_channels = combine_channels(rfp_base_arr, channel_ds_arrs, cell_strains)
+        other = "GFP" if cell_strains == ["6B07", "C3M10"] else "RFP"
+        dapi_clean = combine_cell_positions_and_clusters(denoised_by_channel["DAPI"], denoised_by_channel[other])
+        dapi_positions, dapi_clusters, _, _ = get_cell_positions_and_areas(dapi_clean, dapi_cell_types)
+        all_positions["6B07"] = dapi_positions["6B07"]
+        all_clusters["6B07"] = dapi_clusters["6B07"]
+
+    counts, densities, area_ratios = get_cell_counts_and_densities(all_positions, all_clusters, rfp_particle_area)
+    write_density_info(density_csv, sample_name, densities, area_ratios, counts)
+
+    base = get_rfp_base_arr(denoised_by_channel["RFP"].copy(), cell_strains)
+    combined_channels = combine_channels(base, denoised_by_channel, cell_strains)
     _, _, _, merged_clusters = get_cell_positions_and_areas(combined_channels, BASE_TYPE_MAP, merged=True)
-    write_cell_position_info(master_cell_pos, master_cell_clusters, cell_pos_combined_file_name, rfp_particle_area)
-    merged_file_name = cell_pos_combined_file_name.replace("_cell_pos_combined.csv", "_merged_cell_pos.csv")
-    write_merged_cell_position_info(merged_clusters, merged_file_name, rfp_particle_area)
+    write_cell_position_info(all_positions, all_clusters, combined_csv, rfp_particle_area)
+    write_merged_cell_position_info(merged_clusters, merged_csv, rfp_particle_area)
     return combined_channels, merged_clusters
 
 
