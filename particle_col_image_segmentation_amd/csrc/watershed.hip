@@ -116,42 +116,72 @@ __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__res
     }
 }
 
-// (1) minimax relaxation, tile-local fixed point in LDS
+// (1) minimax relaxation, tile-local fixed point in LDS.  L and the pixel value share one 64-bit LDS word (x = L,
+// y = value): a sweep step is ONE ds_read_b64 instead of two ds_read_b32 -- the kernel is bound by LDS issue, and the
+// b64 form moves twice the bytes per issue slot (odd pitch: conflict-free for row and column sweeps alike).
 __global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restrict__ val, unsigned *__restrict__ L,
                                                         const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
                                                         int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
 {
-    __shared__ unsigned sL[WS_N];
-    __shared__ unsigned sV[WS_N];
+    __shared__ uint2 sLV[WS_N];
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
     if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
     if (threadIdx.x == 0) atomicAdd(any_changed + 1, 1);  // tiles actually processed (measurement: bench.py roofline)
     const int r0 = ty * WS_T, c0 = tx * WS_T;
     const int64_t fbase = (int64_t)b * H * W;
-    ws_load_tile(sL, L + fbase, r0, c0, H, W, WS_INF);
-    ws_load_tile(sV, val + fbase, r0, c0, H, W, WS_INF);
+    for (int i = threadIdx.x; i < WS_S * WS_S; i += 256) {
+        int lr = i / WS_S, lc = i % WS_S;
+        int r = r0 + lr - 1, c = c0 + lc - 1;
+        uint2 lv = make_uint2(WS_INF, WS_INF);
+        if (r >= 0 && r < H && c >= 0 && c < W) {
+            lv.x = L[fbase + (int64_t)r * W + c];
+            lv.y = val[fbase + (int64_t)r * W + c];
+        }
+        sLV[lr * WS_P + lc] = lv;
+    }
     __syncthreads();
     const SweepLine ln = ws_line();
+    unsigned *sLw = reinterpret_cast<unsigned *>(sLV);  // the L half of element i is word 2 * i
     bool changed_any = false;
     for (int iter = 0; iter < 100000; ++iter) {
         bool changed = false;
-        unsigned prev = sL[ln.start];
+        unsigned prev = sLV[ln.start].x;
         int i = ln.start;
 #pragma unroll 8
         for (int k = 0; k < WS_T; ++k) {
             i += ln.step;
-            unsigned cur = sL[i];
-            unsigned cand = max(sV[i], prev);
-            if (cand < cur) { sL[i] = cand; cur = cand; changed = true; }
+            const uint2 lv = sLV[i];
+            unsigned cur = lv.x;
+            const unsigned cand = max(lv.y, prev);
+            if (cand < cur) { sLw[2 * i] = cand; cur = cand; changed = true; }
             prev = cur;
         }
         if (!__syncthreads_or(changed)) break;
         changed_any = true;
     }
     if (!changed_any) return;
-    ws_mark_changed_edges(sL, (const unsigned *)L + fbase, dirty_out, b, tx, ty, tilesX, tilesY, r0, c0, H, W);
+    // mark only the neighbours that share a changed edge (compare with what is still in global memory), then store
+    {
+        const int e = threadIdx.x >> 6, j = threadIdx.x & 63;
+        const int lr = e == 0 ? 1 : (e == 1 ? WS_T : j + 1);
+        const int lc = e == 2 ? 1 : (e == 3 ? WS_T : j + 1);
+        const int r = r0 + lr - 1, c = c0 + lc - 1;
+        bool ch = false;
+        if (r < H && c < W) ch = sLV[lr * WS_P + lc].x != L[fbase + (int64_t)r * W + c];
+        if (__any(ch) && j == 0) {
+            uint8_t *d = dirty_out + (int64_t)b * tilesX * tilesY;
+            if (e == 0 && ty > 0) d[(ty - 1) * tilesX + tx] = 1;
+            if (e == 1 && ty + 1 < tilesY) d[(ty + 1) * tilesX + tx] = 1;
+            if (e == 2 && tx > 0) d[ty * tilesX + tx - 1] = 1;
+            if (e == 3 && tx + 1 < tilesX) d[ty * tilesX + tx + 1] = 1;
+        }
+    }
     __syncthreads();
-    ws_store_tile(sL, L + fbase, r0, c0, H, W);
+    for (int i = threadIdx.x; i < WS_T * WS_T; i += 256) {
+        int lr = i / WS_T, lc = i % WS_T;
+        int r = r0 + lr, c = c0 + lc;
+        if (r < H && c < W) L[fbase + (int64_t)r * W + c] = sLV[(lr + 1) * WS_P + lc + 1].x;
+    }
     if (threadIdx.x == 0) *any_changed = 1;
 }
 
