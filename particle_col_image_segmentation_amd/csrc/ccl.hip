@@ -142,9 +142,11 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(KeyFn keyfn, int *__res
 struct PredAll {
     __device__ __forceinline__ bool operator()(int64_t) const { return true; }
 };
-struct PredNotFlagged {  // root accepted unless flag[root] != 0
+struct PredNotFlagged {  // root accepted unless flag[root] != 0 or its whole frame is switched off (frame_on[b] == 0)
     const uint8_t *flag;
-    __device__ __forceinline__ bool operator()(int64_t gi) const { return flag[gi] == 0; }
+    const int *frame_on;
+    int64_t n;
+    __device__ __forceinline__ bool operator()(int64_t gi) const { return flag[gi] == 0 && frame_on[gi / n] != 0; }
 };
 
 __device__ __forceinline__ int block_exclusive_scan(int v, int *total)
@@ -422,51 +424,79 @@ __global__ void __launch_bounds__(256) ccl_flatten_kernel(int *__restrict__ pare
 }
 
 // ---- local maxima ----------------------------------------------------------
-// candidate: no strictly higher 8-neighbour.  key = candidate ? value-rank key : 0.
+// Both stencil passes stage a 64x16 tile with a 1-pixel halo in LDS (the 8 neighbour reads then hit LDS, and the
+// global read is one coalesced pass with 1.2x halo overhead instead of 9 cached loads per pixel).
+constexpr int LM_TW = 64, LM_TH = 16, LM_SW = LM_TW + 2, LM_SH = LM_TH + 2;
+
+// candidate: no strictly higher 8-neighbour.  key = candidate ? value (0 mapped to INT_MIN) : 0.
 __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__restrict__ img, int *__restrict__ key,
                                                                  int *__restrict__ nonconst, int H, int W)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (r >= H || c >= W) return;
+    __shared__ int tile[LM_SH * LM_SW];
+    const int OUTSIDE = (int)0x80000000;  // image values are > INT_MIN by contract: never higher, never "different"
+    const int r0 = blockIdx.y * LM_TH, c0 = blockIdx.x * LM_TW;
     const int64_t fbase = (int64_t)blockIdx.z * H * W;
-    const int *im = img + fbase;
-    const int v = im[(int64_t)r * W + c];
-    bool cand = true, differs = false;
-    for (int dr = -1; dr <= 1; ++dr)
-        for (int dc = -1; dc <= 1; ++dc) {
-            int rr = r + dr, cc = c + dc;
-            if ((dr == 0 && dc == 0) || rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
-            int q = im[(int64_t)rr * W + cc];
-            cand = cand && (q <= v);
-            differs = differs || (q != v);
-        }
-    // key must be non-zero for candidates and equal exactly when the values are equal:
-    // values are >= INT_MIN; map v -> (v ^ 0x80000000) + 1 would overflow for INT_MAX only.
-    key[fbase + (int64_t)r * W + c] = cand ? (v == 0 ? (int)0x80000000 : v) : 0;
-    if (differs && nonconst[blockIdx.z] == 0) nonconst[blockIdx.z] = 1;
+    for (int i = threadIdx.x; i < LM_SH * LM_SW; i += 256) {
+        int r = r0 + i / LM_SW - 1, c = c0 + i % LM_SW - 1;
+        tile[i] = (r >= 0 && r < H && c >= 0 && c < W) ? img[fbase + (int64_t)r * W + c] : OUTSIDE;
+    }
+    __syncthreads();
+    bool any_differs = false;
+    for (int t = threadIdx.x; t < LM_TH * LM_TW; t += 256) {
+        const int lr = t / LM_TW, lc = t % LM_TW;
+        const int r = r0 + lr, c = c0 + lc;
+        if (r >= H || c >= W) continue;
+        const int i = (lr + 1) * LM_SW + lc + 1;
+        const int v = tile[i];
+        bool cand = true;
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+                if (dr == 0 && dc == 0) continue;
+                const int q = tile[i + dr * LM_SW + dc];
+                cand = cand && (q <= v);
+                any_differs = any_differs || (q != v && q != OUTSIDE);
+            }
+        // key must be non-zero for candidates and equal exactly when the values are equal (values > INT_MIN)
+        key[fbase + (int64_t)r * W + c] = cand ? (v == 0 ? (int)0x80000000 : v) : 0;
+    }
+    if (__any(any_differs) && lane_id() == 0 && nonconst[blockIdx.z] == 0) nonconst[blockIdx.z] = 1;
 }
 
 // bad[root] = 1 if any candidate of the component touches an equal-valued non-candidate
 __global__ void __launch_bounds__(256) locmax_bad_kernel(const int *__restrict__ img, const int *__restrict__ key,
                                                           const int *__restrict__ parent, uint8_t *__restrict__ bad, int H, int W)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (r >= H || c >= W) return;
+    __shared__ int tile[LM_SH * LM_SW];
+    __shared__ uint8_t noncand[LM_SH * LM_SW];  // inside the image and not a candidate
+    const int r0 = blockIdx.y * LM_TH, c0 = blockIdx.x * LM_TW;
     const int64_t fbase = (int64_t)blockIdx.z * H * W;
-    const int p = r * W + c;
-    if (key[fbase + p] == 0) return;
-    const int v = img[fbase + p];
-    bool touches = false;
-    for (int dr = -1; dr <= 1; ++dr)
-        for (int dc = -1; dc <= 1; ++dc) {
-            int rr = r + dr, cc = c + dc;
-            if ((dr == 0 && dc == 0) || rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
-            int64_t q = fbase + (int64_t)rr * W + cc;
-            touches = touches || (img[q] == v && key[q] == 0);
-        }
-    if (touches) bad[fbase + parent[fbase + p]] = 1;
+    for (int i = threadIdx.x; i < LM_SH * LM_SW; i += 256) {
+        int r = r0 + i / LM_SW - 1, c = c0 + i % LM_SW - 1;
+        bool in = r >= 0 && r < H && c >= 0 && c < W;
+        tile[i] = in ? img[fbase + (int64_t)r * W + c] : 0;
+        noncand[i] = in && key[fbase + (int64_t)r * W + c] == 0;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < LM_TH * LM_TW; t += 256) {
+        const int lr = t / LM_TW, lc = t % LM_TW;
+        const int r = r0 + lr, c = c0 + lc;
+        if (r >= H || c >= W) continue;
+        const int i = (lr + 1) * LM_SW + lc + 1;
+        if (noncand[i]) continue;
+        const int v = tile[i];
+        bool touches = false;
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+                if (dr == 0 && dc == 0) continue;
+                const int j = i + dr * LM_SW + dc;
+                touches = touches || (noncand[j] && tile[j] == v);
+            }
+        if (touches) bad[fbase + parent[fbase + (int64_t)r * W + c]] = 1;
+    }
 }
 
 __global__ void __launch_bounds__(256) locmax_out_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ bad,
@@ -477,14 +507,6 @@ __global__ void __launch_bounds__(256) locmax_out_kernel(const int *__restrict__
     int64_t fbase = (int64_t)blockIdx.y * n;
     int p = parent[fbase + i];
     is_max[fbase + i] = (p >= 0 && bad[fbase + p] == 0 && nonconst[blockIdx.y] != 0);
-}
-
-// a constant frame has no maxima: flag every pixel bad so that compaction counts nothing
-__global__ void __launch_bounds__(256) locmax_const_kernel(uint8_t *__restrict__ bad, const int *__restrict__ nonconst, int64_t n)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || nonconst[blockIdx.y] != 0) return;
-    bad[(int64_t)blockIdx.y * n + i] = 1;
 }
 
 // ---- overlap removal (C6) --------------------------------------------------
@@ -651,7 +673,7 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
     }
     PCSEG_CHECK_HIP(hipMemsetAsync(nonconst, 0, sizeof(int) * B, s));
     PCSEG_CHECK_HIP(hipMemsetAsync(bad, 0, (size_t)B * n, s));
-    dim3 g2((W + 63) / 64, (H + 3) / 4, B);
+    dim3 g2((W + LM_TW - 1) / LM_TW, (H + LM_TH - 1) / LM_TH, B);
     PCSEG_LAUNCH(locmax_candidates_kernel, g2, dim3(256), 0, s, img, key, nonconst, H, W);
     PCSEG_CHECK_LAUNCH();
     int rc = ccl_roots<KeyI32, true>(KeyI32{key, W, (int64_t)H * W}, ws.parent, B, H, W, s);
@@ -661,14 +683,12 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
     PCSEG_CHECK_LAUNCH();
     PCSEG_LAUNCH(locmax_bad_kernel, g2, dim3(256), 0, s, img, key, ws.parent, bad, H, W);
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(locmax_const_kernel, g1, dim3(256), 0, s, bad, nonconst, n);
-    PCSEG_CHECK_LAUNCH();
     if (is_max) {
         PCSEG_LAUNCH(locmax_out_kernel, g1, dim3(256), 0, s, ws.parent, bad, nonconst, is_max, n);
         PCSEG_CHECK_LAUNCH();
     }
     if (markers) {
-        rc = ccl_compact(ws.parent, ws.blockcount, ws.nblk, markers, counts, PredNotFlagged{bad}, false, B, H, W, s);
+        rc = ccl_compact(ws.parent, ws.blockcount, ws.nblk, markers, counts, PredNotFlagged{bad, nonconst, n}, false, B, H, W, s);
         if (rc) return rc;
     }
     return PCSEG_OK;
