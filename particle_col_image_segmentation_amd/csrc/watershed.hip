@@ -21,6 +21,7 @@
 //     basins -- ubiquitous in quantised probability maps) are recomputed by an
 //     exact emulation of the reference's binary heap, one workgroup per frame.
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 
@@ -185,6 +186,12 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restric
     if (threadIdx.x == 0) *any_changed = 1;
 }
 
+// kernels of the second level are launched over the flagged frames only: grid index -> frame id through a list
+__device__ __forceinline__ int ws_frame(const int *frame_list, int grid_index)
+{
+    return frame_list ? frame_list[grid_index] : grid_index;
+}
+
 // stage-2 work is restricted to the 64x64 tiles that hold a pixel of an unresolved component (active == nullptr: all)
 __device__ __forceinline__ bool ws_active(const uint8_t *active, int b, int r, int c, int tilesX, int tilesY)
 {
@@ -198,14 +205,14 @@ __device__ __forceinline__ bool ws_active(const uint8_t *active, int b, int r, i
 constexpr int UF_TW = 64, UF_TH = 32, UF_SW = UF_TW + 2, UF_SH = UF_TH + 2;
 
 template <typename KeyT>
-__global__ void __launch_bounds__(256) ws_uf_tile_kernel(const KeyT *__restrict__ K, const int *__restrict__ F,
+__global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__ frame_list, const KeyT *__restrict__ K, const int *__restrict__ F,
                                                           const uint8_t *__restrict__ active, int *__restrict__ parent,
                                                           uint8_t *__restrict__ minmask, int H, int W, int tilesX, int tilesY)
 {
     __shared__ KeyT sK[UF_SH * UF_SW];
     __shared__ int par[UF_TH * UF_TW];
     const KeyT KINF = ~(KeyT)0;
-    const int b = blockIdx.z;
+    const int b = ws_frame(frame_list, blockIdx.z);
     const int r0 = blockIdx.y * UF_TH, c0 = blockIdx.x * UF_TW;
     if (!ws_active(active, b, r0, c0, tilesX, tilesY)) return;  // UF tiles (64x32) nest inside the 64x64 tiles
     const int64_t fbase = (int64_t)b * H * W;
@@ -252,13 +259,13 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const KeyT *__restrict_
 }
 
 // cross-tile links from the neighbour masks the tile pass left behind
-__global__ void __launch_bounds__(256) ws_uf_border_kernel(const uint8_t *__restrict__ minmask, const uint8_t *__restrict__ active,
+__global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict__ frame_list, const uint8_t *__restrict__ minmask, const uint8_t *__restrict__ active,
                                                             int *__restrict__ parent, int H, int W, int tilesX, int tilesY)
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (r >= H || c >= W) return;
-    const int b = blockIdx.z;
+    const int b = ws_frame(frame_list, blockIdx.z);
     if (!ws_active(active, b, r, c, tilesX, tilesY)) return;
     const bool top = (r % UF_TH) == 0 && r > 0;
     const bool left = (c % UF_TW) == 0 && c > 0;
@@ -274,12 +281,12 @@ __global__ void __launch_bounds__(256) ws_uf_border_kernel(const uint8_t *__rest
 }
 
 // flatten + seeds publish their marker id at the root: hi = max id, nlo = max (INT_MAX - id)  (both start at 0)
-__global__ void __launch_bounds__(256) ws_uf_seed_kernel(int *__restrict__ parent, const int *__restrict__ F,
+__global__ void __launch_bounds__(256) ws_uf_seed_kernel(const int *__restrict__ frame_list, int *__restrict__ parent, const int *__restrict__ F,
                                                           const uint8_t *__restrict__ active, int *__restrict__ hi,
                                                           int *__restrict__ nlo, int64_t n, int W, int tilesX, int tilesY)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
+    const int b = ws_frame(frame_list, blockIdx.y);
     if (i >= n || !ws_active(active, b, (int)(i / W), (int)(i % W), tilesX, tilesY)) return;
     int *par = parent + (int64_t)b * n;
     int p = par[i];
@@ -294,14 +301,14 @@ __global__ void __launch_bounds__(256) ws_uf_seed_kernel(int *__restrict__ paren
     }
 }
 
-__global__ void __launch_bounds__(256) ws_uf_assign_kernel(const int *__restrict__ parent, int *__restrict__ F,
+__global__ void __launch_bounds__(256) ws_uf_assign_kernel(const int *__restrict__ frame_list, const int *__restrict__ parent, int *__restrict__ F,
                                                             const uint8_t *__restrict__ active, const int *__restrict__ hi,
                                                             const int *__restrict__ nlo, int *__restrict__ tie_flags,
                                                             uint8_t *__restrict__ mark_active, int64_t n, int W, int tilesX,
                                                             int tilesY)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
+    const int b = ws_frame(frame_list, blockIdx.y);
     const int r = (int)(i / W), c = (int)(i % W);
     if (i >= n || !ws_active(active, b, r, c, tilesX, tilesY)) return;
     const int64_t g = (int64_t)b * n + i;
@@ -360,7 +367,7 @@ __global__ void __launch_bounds__(256) ws_check_kernel(const KeyT *__restrict__ 
 // K2(lake pixel) = min K2 over the neighbours of the same level (the earliest entry floods the whole lake).
 constexpr unsigned WS_SECONDARY = 0xFFFFFFFEu;
 
-__global__ void __launch_bounds__(256) ws_k2_init_kernel(const unsigned *__restrict__ val, const unsigned *__restrict__ L,
+__global__ void __launch_bounds__(256) ws_k2_init_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
                                                           const int *__restrict__ markers, const uint8_t *__restrict__ mask,
                                                           const uint8_t *__restrict__ active, unsigned *__restrict__ K2,
                                                           int H, int W, int tilesX, int tilesY)
@@ -368,7 +375,7 @@ __global__ void __launch_bounds__(256) ws_k2_init_kernel(const unsigned *__restr
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (r >= H || c >= W) return;
-    const int b = blockIdx.z;
+    const int b = ws_frame(frame_list, blockIdx.z);
     if (!ws_active(active, b, r, c, tilesX, tilesY)) return;
     const int64_t i = (int64_t)b * H * W + (int64_t)r * W + c;
     const unsigned l = L[i];
@@ -385,7 +392,7 @@ __global__ void __launch_bounds__(256) ws_k2_init_kernel(const unsigned *__restr
     K2[i] = k;
 }
 
-__global__ void __launch_bounds__(256) ws_k2_relax_kernel(const unsigned *__restrict__ val, const unsigned *__restrict__ L,
+__global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
                                                            unsigned *__restrict__ K2, const uint8_t *__restrict__ active,
                                                            const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
                                                            int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
@@ -393,7 +400,7 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const unsigned *__rest
     __shared__ unsigned sL[WS_N];
     __shared__ unsigned sK[WS_N];
     __shared__ uint8_t sLake[WS_N];
-    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    const int tx = blockIdx.x, ty = blockIdx.y, b = ws_frame(frame_list, blockIdx.z);
     if (!active[((int64_t)b * tilesY + ty) * tilesX + tx]) return;  // K2 is only defined inside the active tiles
     if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
     const int r0 = ty * WS_T, c0 = tx * WS_T;
@@ -435,13 +442,13 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const unsigned *__rest
 // K64 = (L << 32) | K2 inside the active tiles (and the union-find root slots are cleared there); every other pixel of
 // a flagged frame gets (L, worst K2): it can sit in the halo of an active tile, where it must never look like a
 // minimum-key neighbour (it is not in the component, so its L is larger than the minimum anyway)
-__global__ void __launch_bounds__(256) ws_pack_kernel(const unsigned *__restrict__ L, const unsigned *__restrict__ K2,
+__global__ void __launch_bounds__(256) ws_pack_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ L, const unsigned *__restrict__ K2,
                                                        const int *__restrict__ frame_flags, const uint8_t *__restrict__ active,
                                                        unsigned long long *__restrict__ K64, int *__restrict__ hi,
                                                        int *__restrict__ nlo, int64_t n, int W, int tilesX, int tilesY)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
+    const int b = ws_frame(frame_list, blockIdx.y);
     if (i >= n || frame_flags[b] == 0) return;
     const int64_t g = (int64_t)b * n + i;
     if (ws_active(active, b, (int)(i / W), (int)(i % W), tilesX, tilesY)) {
@@ -455,12 +462,12 @@ __global__ void __launch_bounds__(256) ws_pack_kernel(const unsigned *__restrict
 
 // verification builds of the second level run on whole flagged frames: every tile of such a frame becomes active and
 // its labels are reset to the seeds
-__global__ void __launch_bounds__(256) ws_activate_frames_kernel(const int *__restrict__ frame_flags, uint8_t *__restrict__ active,
+__global__ void __launch_bounds__(256) ws_activate_frames_kernel(const int *__restrict__ frame_list, const int *__restrict__ frame_flags, uint8_t *__restrict__ active,
                                                                   const int *__restrict__ markers, const uint8_t *__restrict__ mask,
                                                                   int *__restrict__ out, int64_t n, int W, int tilesX, int tilesY)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
+    const int b = ws_frame(frame_list, blockIdx.y);
     if (i >= n || frame_flags[b] == 0) return;
     active[((int64_t)b * tilesY + (int)(i / W) / WS_T) * tilesX + (int)(i % W) / WS_T] = 1;
     out[(int64_t)b * n + i] = mask[(int64_t)b * n + i] ? markers[(int64_t)b * n + i] : 0;
@@ -574,7 +581,7 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
     if (!check_shape(B, H, W)) return 0;
     size_t n = (size_t)B * H * W;
     int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
-    return 5 * align_up(n * 4) + align_up(n) + 3 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + 2 * align_up(sizeof(int) * B) +
+    return 5 * align_up(n * 4) + align_up(n) + 3 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + 3 * align_up(sizeof(int) * B) +
            align_up(n * 8) + align_up(n * 4);
 }
 
@@ -600,6 +607,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     int *changed = cv.take<int>(16);
     int *flags = cv.take<int>(B);
     int *flags2 = cv.take<int>(B);
+    int *frame_list = cv.take<int>(B);
     unsigned long long *heap_key = cv.take<unsigned long long>(n);  // doubles as K64 of the second-level pass
     unsigned *heap_idx = cv.take<unsigned>(n);                      // doubles as K2
     int *uf_parent = cv.take<int>(n);
@@ -655,18 +663,20 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         const int64_t npx = (int64_t)H * W;
         // label assignment = union-find over "minimum-key neighbour" links.  A component holding two marker ids flags
         // its frame, stays unlabelled and (first level) marks its tiles active for the next level.
-        auto assign_labels = [&](auto *keys, const uint8_t *act, int *out_flags, uint8_t *mark) -> int {
+        auto assign_labels = [&](auto *keys, const int *flist, int nframes, const uint8_t *act, int *out_flags,
+                                 uint8_t *mark) -> int {
             using KeyT = std::remove_const_t<std::remove_pointer_t<decltype(keys)>>;
-            PCSEG_LAUNCH(ws_uf_tile_kernel<KeyT>, ugrid, dim3(256), 0, s, (const KeyT *)keys, (const int *)out, act, uf_parent,
-                         uf_mask, H, W, tilesX, tilesY);
+            const dim3 ug(ugrid.x, ugrid.y, nframes), pg(pgrid.x, pgrid.y, nframes), lg(lgrid.x, nframes);
+            PCSEG_LAUNCH(ws_uf_tile_kernel<KeyT>, ug, dim3(256), 0, s, flist, (const KeyT *)keys, (const int *)out, act,
+                         uf_parent, uf_mask, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            PCSEG_LAUNCH(ws_uf_border_kernel, pgrid, dim3(256), 0, s, (const uint8_t *)uf_mask, act, uf_parent, H, W, tilesX,
-                         tilesY);
-            PCSEG_CHECK_LAUNCH();
-            PCSEG_LAUNCH(ws_uf_seed_kernel, lgrid, dim3(256), 0, s, uf_parent, (const int *)out, act, uf_hi, uf_nlo, npx, W,
+            PCSEG_LAUNCH(ws_uf_border_kernel, pg, dim3(256), 0, s, flist, (const uint8_t *)uf_mask, act, uf_parent, H, W,
                          tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            PCSEG_LAUNCH(ws_uf_assign_kernel, lgrid, dim3(256), 0, s, (const int *)uf_parent, out, act, (const int *)uf_hi,
+            PCSEG_LAUNCH(ws_uf_seed_kernel, lg, dim3(256), 0, s, flist, uf_parent, (const int *)out, act, uf_hi, uf_nlo, npx, W,
+                         tilesX, tilesY);
+            PCSEG_CHECK_LAUNCH();
+            PCSEG_LAUNCH(ws_uf_assign_kernel, lg, dim3(256), 0, s, flist, (const int *)uf_parent, out, act, (const int *)uf_hi,
                          (const int *)uf_nlo, out_flags, mark, npx, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
             return PCSEG_OK;
@@ -677,46 +687,51 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         PCSEG_CHECK_HIP(hipMemsetAsync(active, 0, ntiles, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(uf_hi, 0, sizeof(int) * n, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(uf_nlo, 0, sizeof(int) * n, s));
-        rc = assign_labels((const unsigned *)L, (const uint8_t *)nullptr, flags, active);
+        rc = assign_labels((const unsigned *)L, (const int *)nullptr, B, (const uint8_t *)nullptr, flags, active);
         if (rc) return rc;
         if (verify) {
             PCSEG_LAUNCH(ws_check_kernel<unsigned>, pgrid, dim3(256), 0, s, (const unsigned *)L, (const int *)out, markers, mask,
                          (const int *)nullptr, flags, H, W);
             PCSEG_CHECK_LAUNCH();
         }
-        int any_flag = 0;
+        // flags -> host: which frames need the second level (launched over exactly those frames)
+        std::vector<int> flagged;
         {
-            // flags -> host: is the second-level pass needed at all?
-            static thread_local int host_flags[4096];
-            int nb = B < 4096 ? B : 4096;
-            PCSEG_CHECK_HIP(hipMemcpyAsync(host_flags, flags, sizeof(int) * nb, hipMemcpyDeviceToHost, s));
+            std::vector<int> host_flags(B);
+            PCSEG_CHECK_HIP(hipMemcpyAsync(host_flags.data(), flags, sizeof(int) * B, hipMemcpyDeviceToHost, s));
             PCSEG_CHECK_HIP(hipStreamSynchronize(s));
-            for (int b = 0; b < nb; ++b) any_flag |= host_flags[b];
-            if (B > 4096) any_flag = 1;
+            for (int b = 0; b < B; ++b)
+                if (host_flags[b]) flagged.push_back(b);
         }
+        const int nfl = (int)flagged.size();
+        const int any_flag = nfl > 0;
         if (any_flag) {
             unsigned *K2 = heap_idx;
             unsigned long long *K64 = heap_key;
+            PCSEG_CHECK_HIP(hipMemcpyAsync(frame_list, flagged.data(), sizeof(int) * nfl, hipMemcpyHostToDevice, s));
+            PCSEG_CHECK_HIP(hipStreamSynchronize(s));  // `flagged` is pageable host memory
+            const dim3 pg2(pgrid.x, pgrid.y, nfl), lg2(lgrid.x, nfl), tg2(tilesX, tilesY, nfl);
             if (verify) {
                 // whole flagged frames, so that the explicit per-pixel check of the second level sees valid keys everywhere
-                PCSEG_LAUNCH(ws_activate_frames_kernel, lgrid, dim3(256), 0, s, (const int *)flags, active, markers, mask, out,
-                             npx, W, tilesX, tilesY);
+                PCSEG_LAUNCH(ws_activate_frames_kernel, lg2, dim3(256), 0, s, (const int *)frame_list, (const int *)flags, active,
+                             markers, mask, out, npx, W, tilesX, tilesY);
                 PCSEG_CHECK_LAUNCH();
             }
             // the fixed-point loop below reuses dirtyB: keep the active set in its own buffer
             PCSEG_CHECK_HIP(hipMemcpyAsync(active_tiles, active, ntiles, hipMemcpyDeviceToDevice, s));
-            PCSEG_LAUNCH(ws_k2_init_kernel, pgrid, dim3(256), 0, s, (const unsigned *)val, (const unsigned *)L, markers, mask,
-                         (const uint8_t *)active_tiles, K2, H, W, tilesX, tilesY);
+            PCSEG_LAUNCH(ws_k2_init_kernel, pg2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
+                         (const unsigned *)L, markers, mask, (const uint8_t *)active_tiles, K2, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
             rc = iterate(active_tiles, [&](uint8_t *din, uint8_t *dout) {
-                PCSEG_LAUNCH(ws_k2_relax_kernel, tgrid, dim3(256), 0, s, (const unsigned *)val, (const unsigned *)L, K2,
-                             (const uint8_t *)active_tiles, din, dout, changed, H, W, tilesX, tilesY);
+                PCSEG_LAUNCH(ws_k2_relax_kernel, tg2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
+                             (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, changed, H, W, tilesX, tilesY);
             });
             if (rc) return rc;
-            PCSEG_LAUNCH(ws_pack_kernel, lgrid, dim3(256), 0, s, (const unsigned *)L, (const unsigned *)K2, (const int *)flags,
-                         (const uint8_t *)active_tiles, K64, uf_hi, uf_nlo, npx, W, tilesX, tilesY);
+            PCSEG_LAUNCH(ws_pack_kernel, lg2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)L, (const unsigned *)K2,
+                         (const int *)flags, (const uint8_t *)active_tiles, K64, uf_hi, uf_nlo, npx, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            rc = assign_labels((const unsigned long long *)K64, (const uint8_t *)active_tiles, flags2, (uint8_t *)nullptr);
+            rc = assign_labels((const unsigned long long *)K64, (const int *)frame_list, nfl, (const uint8_t *)active_tiles,
+                               flags2, (uint8_t *)nullptr);
             if (rc) return rc;
             if (verify) {
                 PCSEG_LAUNCH(ws_check_kernel<unsigned long long>, pgrid, dim3(256), 0, s, (const unsigned long long *)K64,
