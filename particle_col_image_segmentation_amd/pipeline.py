@@ -67,7 +67,8 @@ class FramePipeline:
         # the many short launches and polls of the watershed's late rounds overlap with the first chain's kernels.
         cur = torch.cuda.current_stream()
         if self._streams is None or self._streams[0].device != stack.device:
-            self._streams = (torch.cuda.Stream(device=stack.device), torch.cuda.Stream(device=stack.device))
+            # the refinement chain is the critical path: its stream gets the higher priority
+            self._streams = (torch.cuda.Stream(device=stack.device, priority=0), torch.cuda.Stream(device=stack.device, priority=-1))
         s1, s2 = self._streams
         s1.wait_stream(cur)
         s2.wait_stream(cur)
