@@ -82,8 +82,32 @@ def cpu_baseline(size, n_frames):
                       "(%.2f s/frame/core)" % (n, size, size, cores, wall, sum(per) / len(per))}
 
 
+class _StdoutToStderr:
+    """Library banners (RCCL prints its host / library path on stdout at init) must not pollute the one JSON line:
+    route file descriptor 1 to stderr while the benchmark runs, restore it for the final print."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main():
     args = parse_args()
+    with _StdoutToStderr():
+        line = _run(args)
+    if line is not None:
+        print(line, flush=True)
+
+
+def _run(args):
     import torch
     import torch.distributed as dist
 
@@ -194,10 +218,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, args.cpu_frames)
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":
