@@ -312,6 +312,8 @@ class ClassTables:
                 particle[val] = 1
         if len(self.slot_names) > 4:
             raise ValueError("at most 4 cell types")
+        if any(not (0 <= int(v) < 64) for v, t in cell_types.items() if t in cell_type_names or t == "Particle"):
+            raise ValueError("cell / particle class values must be below 64 (they index a 64-bit class set)")
         self.slot = slot
         self.particle = particle
         self.min_cell = np.array([min_cell_area[n] for n in self.slot_names] or [0], np.int32)
