@@ -479,12 +479,174 @@ __global__ void ws_set_flags_kernel(int *flags, int B, int v)
     if (i < B) flags[i] = v;
 }
 
-// exact emulation of the reference's heap-driven flood for flagged frames
+// ---- exact emulation of the reference's heap-driven flood for flagged frames
+//
+// The reference's queue is a binary heap ordered by (value, age) in which all seeds carry age 0: seeds of equal value
+// leave it in an order only the heap's own sift rules define, so the emulation has to be the literal binary heap, not
+// just any priority queue.  A lone lane would pay one memory round trip and a few dozen instructions per heap level
+// (one wave issues an instruction every four cycles at best); instead one WAVE runs one frame and works on five
+// levels at a time:
+//   * heap slots 1..EX_LDS-1 (the top levels) live in LDS, deeper slots in the workspace;
+//   * sift-down: lane r of 1..31 owns relative node r of the 5-level subtree under the current hole, loads both of
+//     its children and decides -- against the wave-uniform key being placed -- which child would move up.  The path
+//     is then five v_readlane hops, and all lanes on it write their slot at once;
+//   * sift-up: lane s loads ancestor c >> s, one ballot gives the number of levels the new key climbs;
+//   * the four neighbours of the popped pixel are examined by four lanes while the sift-down is in flight.
+// Comparisons and moves are those of the sequential heappush / heappop, so the pop order is identical.
+constexpr int EX_LDS = 8192;  // 2^13: levels 0..12 (96 KB of the CU's 160 KB)
+
+struct ExactHeap {
+    unsigned long long *lk;  // LDS keys   (slot d at lk[d], slot 0 unused)
+    unsigned *lx;            // LDS pixel indices
+    unsigned long long *gk;  // workspace keys (slot d at gk[d])
+    unsigned *gx;
+    int items;
+    unsigned long long tail_key;  // content of slot `items` (the entry the next heappop re-inserts), kept in registers:
+    unsigned tail_idx;            // known after a push, fetched ahead of time at the end of a pop
+
+    __device__ __forceinline__ unsigned long long key_at(int d) const
+    {
+        return d < EX_LDS ? lk[d] : gk[d];
+    }
+    __device__ __forceinline__ unsigned idx_at(int d) const
+    {
+        return d < EX_LDS ? lx[d] : gx[d];
+    }
+    __device__ __forceinline__ void put(int d, unsigned long long k, unsigned x) const
+    {
+        if (d < EX_LDS) {
+            lk[d] = k;
+            lx[d] = x;
+        } else {
+            gk[d] = k;
+            gx[d] = x;
+        }
+    }
+};
+
+__device__ __forceinline__ unsigned lane_u32(unsigned v, int lane)
+{
+    return (unsigned)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(lane));
+}
+__device__ __forceinline__ unsigned long long lane_u64(unsigned long long v, int lane)
+{
+    const int l = __builtin_amdgcn_readfirstlane(lane);
+    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// slot of relative position `rel` (1 = the node itself, children of r are 2r and 2r+1) in the subtree rooted at `j`
+__device__ __forceinline__ long long ex_slot(int j, int rel)
+{
+    const int lv = 31 - __clz(rel);
+    return ((long long)j << lv) + (rel - (1 << lv));
+}
+
+// heappush: the new entry starts in slot c = ++items and climbs while it is smaller than its parent
+__device__ __forceinline__ void ex_push(ExactHeap &h, unsigned long long key, unsigned idx)
+{
+    asm volatile("" ::: "memory");  // lanes hand heap slots to each other: no value may be carried across in registers
+    const int t = threadIdx.x;
+    const int c = ++h.items;
+    const int a = t < 31 ? (c >> t) : 0;  // lane s >= 1 owns ancestor c >> s
+    unsigned long long ak = 0;            // 0: never above the key -> the climb stops there (also for absent ancestors)
+    unsigned ax = 0;
+    if (t >= 1 && a >= 1) {
+        ak = h.key_at(a);
+        ax = h.idx_at(a);
+    }
+    const unsigned long long climbs = __ballot(t >= 1 && a >= 1 && key < ak) >> 1;
+    const int m = __ffsll((long long)~climbs) - 1;  // consecutive ancestors above the key
+    if (t >= 1 && t <= m) h.put(c >> (t - 1), ak, ax);
+    if (t == 0) h.put(c >> m, key, idx);
+    // slot c now holds the new entry, or its old parent if the entry climbed
+    h.tail_key = m ? lane_u64(ak, 1) : key;
+    h.tail_idx = m ? lane_u32(ax, 1) : idx;
+}
+
+// heappop after the caller has read the root: the last entry is re-inserted from the root downwards.
+// Lane r = 1..63 owns relative node r of the six levels under the hole and loads the pair of its children (adjacent
+// slots 2d, 2d+1: one 16-byte key load, one 8-byte index load).  Windows advance by exactly six levels, so with
+// EX_LDS = 2^13 a window reads either LDS only (hole on level 0 or 6) or the workspace only (hole on level 12, 18, ..).
+template <bool FROM_LDS>
+__device__ __forceinline__ void ex_children(const ExactHeap &h, long long d, unsigned long long &lkey, unsigned long long &rkey,
+                                            unsigned &lidx, unsigned &ridx)
+{
+    lkey = rkey = ~0ull;
+    lidx = ridx = 0;
+    if (2 * d <= h.items) {
+        typedef unsigned long long __attribute__((ext_vector_type(2))) key2_t;
+        typedef unsigned __attribute__((ext_vector_type(2))) idx2_t;
+        typedef key2_t __attribute__((aligned(8))) key2_glb_t;  // workspace slots start at an odd element
+        typedef idx2_t __attribute__((aligned(4))) idx2_glb_t;
+        key2_t k;
+        idx2_t x;
+        if (FROM_LDS) {
+            k = *(const key2_t *)(h.lk + 2 * d);
+            x = *(const idx2_t *)(h.lx + 2 * d);
+        } else {
+            k = *(const key2_glb_t *)(h.gk + 2 * d);
+            x = *(const idx2_glb_t *)(h.gx + 2 * d);
+        }
+        lkey = k.x;
+        lidx = x.x;
+        if (2 * d + 1 <= h.items) {
+            rkey = k.y;
+            ridx = x.y;
+        }
+    }
+}
+
+__device__ __forceinline__ void ex_pop(ExactHeap &h)
+{
+    asm volatile("" ::: "memory");
+    const int t = threadIdx.x;
+    if (--h.items == 0) return;
+    const unsigned long long key = h.tail_key;
+    const unsigned idx = h.tail_idx;
+    int j = 1;  // slot of the hole
+    for (;;) {
+        const long long d = t >= 1 ? ex_slot(j, t) : (long long)h.items + 1;
+        unsigned long long lkey, rkey;
+        unsigned lidx, ridx;
+        if (j < EX_LDS / 64) ex_children<true>(h, d, lkey, rkey, lidx, ridx);
+        else ex_children<false>(h, d, lkey, rkey, lidx, ridx);
+        // which child would move into this node if the key being placed arrived here
+        int next = 0;
+        unsigned long long sk = key;
+        unsigned sx = 0;
+        if (lkey < sk) { next = 2 * t; sk = lkey; sx = lidx; }
+        if (rkey < sk) { next = 2 * t + 1; sk = rkey; sx = ridx; }
+        // follow the path from the hole (six hops at most) and collect the lanes on it
+        unsigned long long on_path = 0;
+        int rel = 1;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int nx = (int)lane_u32((unsigned)next, rel);
+            if (nx == 0) break;
+            on_path |= 1ull << rel;
+            rel = nx;
+        }
+        if ((on_path >> t) & 1) h.put((int)d, sk, sx);
+        asm volatile("" ::: "memory");
+        j = (int)ex_slot(j, rel);
+        if (rel < 64 || 2 * (long long)j > h.items) break;
+    }
+    if (t == 0) h.put(j, key, idx);
+    asm volatile("" ::: "memory");
+    // the entry the next heappop would re-insert; in flight while the caller looks at the popped pixel
+    h.tail_key = h.key_at(h.items);
+    h.tail_idx = h.idx_at(h.items);
+}
+
 __global__ void __launch_bounds__(256) ws_exact_kernel(const unsigned *__restrict__ val, const int *__restrict__ markers,
                                                         const uint8_t *__restrict__ mask, int *__restrict__ out,
                                                         const int *__restrict__ flags, unsigned long long *__restrict__ heap_key,
                                                         unsigned *__restrict__ heap_idx, int H, int W)
 {
+    __shared__ __attribute__((aligned(16))) unsigned long long lds_key[EX_LDS];
+    __shared__ __attribute__((aligned(16))) unsigned lds_idx[EX_LDS];
     const int b = blockIdx.x;
     if (flags[b] == 0) return;
     const int64_t n = (int64_t)H * W;
@@ -492,70 +654,50 @@ __global__ void __launch_bounds__(256) ws_exact_kernel(const unsigned *__restric
     const int *mk = markers + (int64_t)b * n;
     const uint8_t *ms = mask + (int64_t)b * n;
     int *o = out + (int64_t)b * n;
-    unsigned long long *hk = heap_key + (int64_t)b * n;
-    unsigned *hi = heap_idx + (int64_t)b * n;
     for (int64_t i = threadIdx.x; i < n; i += 256) o[i] = ms[i] ? mk[i] : 0;
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    int64_t items = 0;
+    if (threadIdx.x >= WAVE) return;
+    const int t = threadIdx.x;
+    // slot d (1-based) of the heap is element d - 1 of the sequential heap.  Slots >= EX_LDS live in the workspace, which
+    // holds n elements per frame: slot d -> element d - 1, so that slot n (every pixel is pushed at most once) still fits
+    ExactHeap h{lds_key, lds_idx, heap_key + (int64_t)b * n - 1, heap_idx + (int64_t)b * n - 1, 0, 0ull, 0u};
+    for (int64_t base = 0; base < n; base += WAVE) {
+        const int64_t i = base + t;
+        const int seed = i < n ? o[i] : 0;
+        const unsigned sv = i < n ? v[i] : 0u;
+        unsigned long long m = __ballot(seed != 0);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const unsigned si = (unsigned)(base + l);
+            ex_push(h, (unsigned long long)lane_u32(sv, l) << 32, ((si / (unsigned)W) << 16) | (si % (unsigned)W));
+        }
+    }
     unsigned age = 0;
-    auto push = [&](unsigned value, unsigned a, unsigned idx) {
-        unsigned long long key = ((unsigned long long)value << 32) | a;
-        int64_t child = items++;
-        while (child > 0) {
-            int64_t parent = (child + 1) / 2 - 1;
-            unsigned long long pk = hk[parent];
-            if (key < pk) {
-                hk[child] = pk;
-                hi[child] = hi[parent];
-                child = parent;
-            } else break;
+    while (h.items > 0) {
+        const unsigned e_idx = lane_u32(h.idx_at(1), 0);
+        const int r0 = (int)(e_idx >> 16), c0 = (int)(e_idx & 0xFFFFu);  // heap entries carry (row << 16) | col
+        // lanes 0..3 look at the neighbours in the reference's order (up, left, right, down) while the heap is repaired
+        const int rr = r0 + (t == 0 ? -1 : t == 3 ? 1 : 0), cc = c0 + (t == 1 ? -1 : t == 2 ? 1 : 0);
+        bool open = false;
+        unsigned qv = 0;
+        const int64_t q = (int64_t)rr * W + cc;
+        if (t < 4 && rr >= 0 && rr < H && cc >= 0 && cc < W) {
+            const uint8_t in_mask = ms[q];  // three independent loads, in flight together
+            const int taken = o[q];
+            qv = v[q];
+            open = in_mask != 0 && taken == 0;
         }
-        hk[child] = key;
-        hi[child] = idx;
-    };
-    for (int64_t i = 0; i < n; ++i)
-        if (o[i] != 0) push(v[i], 0u, (unsigned)i);
-    while (items > 0) {
-        const unsigned e_idx = hi[0];
-        --items;
-        if (items > 0) {
-            // move the last element to the root and sift it down (reference heappop)
-            unsigned long long key = hk[items];
-            unsigned idx = hi[items];
-            int64_t i = 0;
-            for (;;) {
-                int64_t l = 2 * i + 1, r = 2 * i + 2, smallest = i;
-                unsigned long long sk = key;
-                if (l < items) {
-                    unsigned long long lk = hk[l];
-                    if (lk < sk) { smallest = l; sk = lk; }
-                    if (r < items) {
-                        unsigned long long rk = hk[r];
-                        if (rk < sk) { smallest = r; sk = rk; }
-                    }
-                } else break;
-                if (smallest != i) {
-                    hk[i] = sk;
-                    hi[i] = hi[smallest];
-                    i = smallest;
-                } else break;
-            }
-            hk[i] = key;
-            hi[i] = idx;
-        }
-        const int r0 = (int)(e_idx / (unsigned)W), c0 = (int)(e_idx % (unsigned)W);
-        const int lab = o[e_idx];
-        const int dr[4] = {-1, 0, 0, 1}, dc[4] = {0, -1, 1, 0};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int rr = r0 + dr[k], cc = c0 + dc[k];
-            if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
-            int64_t q = (int64_t)rr * W + cc;
-            if (!ms[q] || o[q] != 0) continue;
+        const int lab = o[(int64_t)r0 * W + c0];
+        ex_pop(h);
+        unsigned long long m = __ballot(open);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const unsigned qi = lane_u32((unsigned)q, l);
             ++age;
-            o[q] = lab;
-            push(v[q], age, (unsigned)q);
+            if (t == 0) o[qi] = lab;
+            ex_push(h, ((unsigned long long)lane_u32(qv, l) << 32) | age, lane_u32(((unsigned)rr << 16) | (unsigned)cc, l));
         }
     }
 }

@@ -221,6 +221,30 @@ def test_watershed_golden(ops, primitives, mode):
         assert n_flagged > 0  # quantised cases must have gone through the exact path
 
 
+def test_watershed_exact_path_deep_heap(ops):
+    """Mode 1 = the heap emulation alone, on quantised frames large enough for the heap to outgrow its LDS levels
+    (4095 slots) so that the workspace levels, the 5-level descents and long sift-ups are all exercised."""
+    from particle_col_image_segmentation_amd import synth
+    st = synth.gen_batch(81, 2, 448, 576, ties=True)
+    bm = np.ascontiguousarray(st[:, 3])
+    bm[1] = np.round(bm[1] * 6) / 6  # very few levels: huge plateaus, heap of tens of thousands of entries
+    refs = [orc.refine_boundaries(b) for b in bm]
+    mk = np.stack([r["markers"] for r in refs])
+    ms = np.stack([r["binary_mask"] for r in refs])
+    out, _ = ops.watershed(dev(bm), dev(mk), dev(ms), mode=1)
+    for i in range(2):
+        np.testing.assert_array_equal(host(out)[i], refs[i]["labels"])
+    # a flood from a handful of seeds over a flat image: the queue holds whole BFS fronts of one value
+    flat = np.full((1, 300, 700), 0.25, np.float32)
+    mk1 = np.zeros((1, 300, 700), np.int32)
+    for k, (r, c) in enumerate([(5, 5), (150, 350), (299, 699), (20, 600), (280, 30)]):
+        mk1[0, r, c] = k + 1
+    ms1 = np.ones((1, 300, 700), bool)
+    ms1[0, 100:200, 340] = False
+    out, _ = ops.watershed(dev(flat), dev(mk1), dev(ms1), mode=1)
+    np.testing.assert_array_equal(host(out)[0], orc.watershed(flat[0], mk1[0], ms1[0]))
+
+
 def test_watershed_parallel_path_is_proven(ops):
     """Tie-free frames: the parallel flood alone (mode 2) must already be exact wherever it says so."""
     from particle_col_image_segmentation_amd import synth
