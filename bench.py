@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = 2 per core)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event table to stderr")
+    ap.add_argument("--levels", type=int, default=0,
+                    help="NOT the headline workload: quantise the boundary plane to k/LEVELS (random-forest-like vote "
+                         "fractions); every frame then floods through ties and takes the watershed's exact path")
     return ap.parse_args()
 
 
@@ -130,6 +133,8 @@ def _run(args):
     B, H, W = args.batch, args.size, args.size
     lib = _lib.load()
     stack = synth.gen_batch_torch(10_000 + rank * B, B, H, W, dev)
+    if args.levels > 0:
+        stack[:, 3] = torch.round(stack[:, 3] * args.levels) / args.levels
     pipe = FramePipeline(dict(synth.CELL_TYPES_5))
     res = None
     # setup (not warmup): two priming passes so that torch's caching allocator holds every workspace block before the
@@ -202,7 +207,8 @@ def _run(args):
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 planes / u8 class maps / int32 labels / f64 ROI sums", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: batch of %d frames %dx%dx5 float32 per GPU, full kernel chain, "
+            "config": {"workload": ("BASELINE config 2" if not args.levels else "boundary plane quantised to k/%d" % args.levels)
+                                   + ": batch of %d frames %dx%dx5 float32 per GPU, full kernel chain, "
                                    "inputs resident in HBM" % (B, H, W),
                        "frames_per_gpu": B, "height": H, "width": W, "planes": 5, "parallelism": "frames x%d" % world,
                        "tie_fallback_frames_last_step": tie_frames, "gathered_roi_rows": n_rois},
