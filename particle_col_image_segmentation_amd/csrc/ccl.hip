@@ -105,17 +105,32 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(KeyFn keyfn, int *__restr
     }
 }
 
+// Threads enumerate the tile-border pixels densely (a per-pixel grid would leave one or two working lanes per wave,
+// each with a chain of dependent finds): first the rows that start a tile row, lanes along the row; then, for every
+// other row, the columns either side of a vertical tile edge, lanes along the column.
 template <typename KeyFn, bool CONN8>
 __global__ void __launch_bounds__(256) ccl_border_kernel(KeyFn keyfn, int *__restrict__ parent, int H, int W)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (r >= H || c >= W) return;
+    const int n_top_rows = (H - 1) / CCL_TH, n_edges = (W - 1) / CCL_TW;
+    const int n_cols = CONN8 ? 2 * n_edges : n_edges;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int r, c;
+    if (i < n_top_rows * W) {
+        r = (i / W + 1) * CCL_TH;
+        c = i % W;
+    } else {
+        i -= n_top_rows * W;
+        if (i >= n_cols * H) return;
+        const int j = i / H;
+        r = i % H;
+        if ((r % CCL_TH) == 0 && r > 0) return;  // handled with its row above
+        c = CONN8 ? ((j >> 1) + 1) * CCL_TW - (j & 1) : (j + 1) * CCL_TW;
+    }
     const bool top = (r % CCL_TH) == 0 && r > 0;
     const bool left = (c % CCL_TW) == 0 && c > 0;
     const bool right = (c % CCL_TW) == CCL_TW - 1 && c + 1 < W;
     if (!top && !left && !(CONN8 && right && r > 0)) return;
-    const int b = blockIdx.z;
+    const int b = blockIdx.y;
     const int64_t fbase = (int64_t)b * H * W;
     int *par = parent + fbase;
     const int p = r * W + c;
@@ -282,7 +297,8 @@ static int ccl_roots(KeyFn keyfn, int *parent, int B, int H, int W, hipStream_t 
     PCSEG_LAUNCH((ccl_tile_kernel<KeyFn, CONN8>), tgrid, dim3(256), 0, s, keyfn, parent, H, W);
     PCSEG_CHECK_LAUNCH();
     if (tgrid.x > 1 || tgrid.y > 1) {
-        dim3 bgrid((W + 63) / 64, (H + 3) / 4, B);
+        const int64_t border_px = (int64_t)((H - 1) / CCL_TH) * W + (int64_t)(CONN8 ? 2 : 1) * ((W - 1) / CCL_TW) * H;
+        dim3 bgrid((unsigned)((border_px + 255) / 256), B);
         PCSEG_LAUNCH((ccl_border_kernel<KeyFn, CONN8>), bgrid, dim3(256), 0, s, keyfn, parent, H, W);
         PCSEG_CHECK_LAUNCH();
     }

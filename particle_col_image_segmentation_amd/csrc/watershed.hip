@@ -262,10 +262,22 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__
 __global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict__ frame_list, const uint8_t *__restrict__ minmask, const uint8_t *__restrict__ active,
                                                             int *__restrict__ parent, int H, int W, int tilesX, int tilesY)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (r >= H || c >= W) return;
-    const int b = ws_frame(frame_list, blockIdx.z);
+    // dense enumeration of the border pixels: rows that start a tile row (lanes along the row), then the first column
+    // of every tile column for the remaining rows (lanes along the column)
+    const int n_top_rows = (H - 1) / UF_TH, n_edges = (W - 1) / UF_TW;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int r, c;
+    if (i < n_top_rows * W) {
+        r = (i / W + 1) * UF_TH;
+        c = i % W;
+    } else {
+        i -= n_top_rows * W;
+        if (i >= n_edges * H) return;
+        r = i % H;
+        if ((r % UF_TH) == 0 && r > 0) return;  // handled with its row above
+        c = (i / H + 1) * UF_TW;
+    }
+    const int b = ws_frame(frame_list, blockIdx.y);
     if (!ws_active(active, b, r, c, tilesX, tilesY)) return;
     const bool top = (r % UF_TH) == 0 && r > 0;
     const bool left = (c % UF_TW) == 0 && c > 0;
@@ -808,13 +820,17 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         auto assign_labels = [&](auto *keys, const int *flist, int nframes, const uint8_t *act, int *out_flags,
                                  uint8_t *mark) -> int {
             using KeyT = std::remove_const_t<std::remove_pointer_t<decltype(keys)>>;
-            const dim3 ug(ugrid.x, ugrid.y, nframes), pg(pgrid.x, pgrid.y, nframes), lg(lgrid.x, nframes);
+            const dim3 ug(ugrid.x, ugrid.y, nframes), lg(lgrid.x, nframes);
+            const int64_t border_px = (int64_t)((H - 1) / UF_TH) * W + (int64_t)((W - 1) / UF_TW) * H;
+            const dim3 bg((unsigned)((border_px + 255) / 256), nframes);
             PCSEG_LAUNCH(ws_uf_tile_kernel<KeyT>, ug, dim3(256), 0, s, flist, (const KeyT *)keys, (const int *)out, act,
                          uf_parent, uf_mask, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            PCSEG_LAUNCH(ws_uf_border_kernel, pg, dim3(256), 0, s, flist, (const uint8_t *)uf_mask, act, uf_parent, H, W,
-                         tilesX, tilesY);
-            PCSEG_CHECK_LAUNCH();
+            if (border_px > 0) {
+                PCSEG_LAUNCH(ws_uf_border_kernel, bg, dim3(256), 0, s, flist, (const uint8_t *)uf_mask, act, uf_parent, H, W,
+                             tilesX, tilesY);
+                PCSEG_CHECK_LAUNCH();
+            }
             PCSEG_LAUNCH(ws_uf_seed_kernel, lg, dim3(256), 0, s, flist, uf_parent, (const int *)out, act, uf_hi, uf_nlo, npx, W,
                          tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
