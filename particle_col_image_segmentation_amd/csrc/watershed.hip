@@ -201,8 +201,56 @@ __device__ __forceinline__ bool ws_active(const uint8_t *active, int b, int r, i
 // (2) label assignment by union-find: every non-seed reachable pixel is united with ALL its
 // neighbours that hold the minimum neighbour key.  If no pixel has minimum-key neighbours in two basins (the proof
 // check's premise) the components are exactly the basins, each holding the seeds of one marker; a component that
-// holds two different marker ids flags the frame instead.  One LDS tile pass + one border pass + flatten, like A2.
+// holds two different marker ids flags the frame instead.  One LDS tile pass + one border pass, like A2 -- but the
+// union-find orders its nodes by a VIRTUAL index in which every seed precedes every other pixel (seed: index,
+// non-seed: index + UF_NS).  Roots are minima, so the root of a component that holds a seed IS a seed, and a pixel's
+// label is simply out[root]: no separate pass that publishes marker ids at the roots.
 constexpr int UF_TW = 64, UF_TH = 32, UF_SW = UF_TW + 2, UF_SH = UF_TH + 2;
+constexpr int UF_LNS = UF_TW * UF_TH;  // non-seed offset of tile-local virtual indices
+constexpr int UF_NS = 1 << 30;         // non-seed offset of frame-wide virtual indices (H * W < 2^30)
+
+__device__ __forceinline__ int vfind_lds(volatile int *par, int v)
+{
+    int p;
+    while ((p = par[v & (UF_LNS - 1)]) != v) v = p;
+    return v;
+}
+__device__ __forceinline__ void vunite_lds(int *par, int a, int b)
+{
+    for (;;) {
+        a = vfind_lds(par, a);
+        b = vfind_lds(par, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(&par[a & (UF_LNS - 1)], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+__device__ __forceinline__ int vfind_glb(int *par, int v)
+{
+    int p;
+    while ((p = ld_agent(par + (v & (UF_NS - 1)))) != v) {
+        int g = ld_agent(par + (p & (UF_NS - 1)));
+        if (g != p) __hip_atomic_store(par + (v & (UF_NS - 1)), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = g;
+    }
+    return v;
+}
+// p, q: pixel indices; the walk starts from their parents, which are virtual indices of nodes in the same sets
+__device__ __forceinline__ void vunite_glb(int *par, int p, int q)
+{
+    int a = ld_agent(par + p), b = ld_agent(par + q);
+    for (;;) {
+        a = vfind_glb(par, a);
+        b = vfind_glb(par, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(par + (a & (UF_NS - 1)), b);
+        if (old == a) return;
+        a = old;
+    }
+}
 
 template <typename KeyT>
 __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__ frame_list, const KeyT *__restrict__ K, const int *__restrict__ F,
@@ -221,29 +269,41 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__
         sK[i] = (r >= 0 && r < H && c >= 0 && c < W) ? K[fbase + (int64_t)r * W + c] : KINF;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < UF_TH * UF_TW; t += 256) {
-        int i = (t / UF_TW + 1) * UF_SW + t % UF_TW + 1;
-        par[t] = ((unsigned)(sK[i] >> (8 * sizeof(KeyT) - 32)) == WS_INF) ? -1 : t;
+    int self[UF_LNS / 256];  // own virtual index of the pixels this thread handles (-1: unreachable / outside)
+#pragma unroll
+    for (int k = 0; k < UF_LNS / 256; ++k) {
+        const int t = threadIdx.x + k * 256;
+        const int lr = t / UF_TW, lc = t % UF_TW;
+        const int r = r0 + lr, c = c0 + lc;
+        const int i = (lr + 1) * UF_SW + lc + 1;
+        int v = -1;
+        if ((unsigned)(sK[i] >> (8 * sizeof(KeyT) - 32)) != WS_INF)  // reachable => inside the frame
+            v = F[fbase + (int64_t)r * W + c] != 0 ? t : t + UF_LNS;  // labelled pixels (seeds) order first
+        self[k] = v;
+        par[t] = v;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < UF_TH * UF_TW; t += 256) {
+#pragma unroll
+    for (int k = 0; k < UF_LNS / 256; ++k) {
+        const int t = threadIdx.x + k * 256;
         const int lr = t / UF_TW, lc = t % UF_TW;
         const int r = r0 + lr, c = c0 + lc;
         if (r >= H || c >= W) continue;
         // which neighbours hold the minimum neighbour key (bit0 up, 1 left, 2 right, 3 down); 0 for seeds / unreachable.
         // Written for the border pass, which then needs two bytes per cross-tile pair instead of ten keys.
         uint8_t m8 = 0;
-        if (par[t] >= 0 && F[fbase + (int64_t)r * W + c] == 0) {  // seeds take no label from neighbours
+        if (self[k] >= UF_LNS) {  // seeds take no label from neighbours
             const int i = (lr + 1) * UF_SW + lc + 1;
             const KeyT ku = sK[i - UF_SW], kl = sK[i - 1], kr = sK[i + 1], kd = sK[i + UF_SW];
             const KeyT m = min(min(ku, kd), min(kl, kr));
             if (m != KINF) m8 = (ku == m ? 1 : 0) | (kl == m ? 2 : 0) | (kr == m ? 4 : 0) | (kd == m ? 8 : 0);
         }
         minmask[fbase + (int64_t)r * W + c] = m8;
-        if ((m8 & 1) && lr > 0) unite_lds(par, t, t - UF_TW);
-        if ((m8 & 2) && lc > 0) unite_lds(par, t, t - 1);
-        if ((m8 & 4) && lc < UF_TW - 1) unite_lds(par, t, t + 1);
-        if ((m8 & 8) && lr < UF_TH - 1) unite_lds(par, t, t + UF_TW);
+        // a neighbour's current parent is a node of the neighbour's set: a valid starting point for the union
+        if ((m8 & 1) && lr > 0) vunite_lds(par, self[k], par[t - UF_TW]);
+        if ((m8 & 2) && lc > 0) vunite_lds(par, self[k], par[t - 1]);
+        if ((m8 & 4) && lc < UF_TW - 1) vunite_lds(par, self[k], par[t + 1]);
+        if ((m8 & 8) && lr < UF_TH - 1) vunite_lds(par, self[k], par[t + UF_TW]);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < UF_TH * UF_TW; t += 256) {
@@ -251,8 +311,9 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__
         if (r >= H || c >= W) continue;
         int v = -1;
         if (par[t] >= 0) {
-            int root = find_lds(par, t);
-            v = (r0 + root / UF_TW) * W + c0 + root % UF_TW;
+            const int root = vfind_lds(par, par[t]);
+            const int lt = root & (UF_LNS - 1);
+            v = ((r0 + lt / UF_TW) * W + c0 + lt % UF_TW) | (root >= UF_LNS ? UF_NS : 0);
         }
         parent[fbase + (int64_t)r * W + c] = v;
     }
@@ -287,57 +348,58 @@ __global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict
     const int p = r * W + c;
     const uint8_t mp = minmask[fbase + p];
     if (top && ws_active(active, b, r - 1, c, tilesX, tilesY) && ((mp & 1) || (minmask[fbase + p - W] & 8)))
-        unite_glb(par, p, p - W);
+        vunite_glb(par, p, p - W);
     if (left && ws_active(active, b, r, c - 1, tilesX, tilesY) && ((mp & 2) || (minmask[fbase + p - 1] & 4)))
-        unite_glb(par, p, p - 1);
+        vunite_glb(par, p, p - 1);
 }
 
-// flatten + seeds publish their marker id at the root: hi = max id, nlo = max (INT_MAX - id)  (both start at 0)
-__global__ void __launch_bounds__(256) ws_uf_seed_kernel(const int *__restrict__ frame_list, int *__restrict__ parent, const int *__restrict__ F,
-                                                          const uint8_t *__restrict__ active, int *__restrict__ hi,
-                                                          int *__restrict__ nlo, int64_t n, int W, int tilesX, int tilesY)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = ws_frame(frame_list, blockIdx.y);
-    if (i >= n || !ws_active(active, b, (int)(i / W), (int)(i % W), tilesX, tilesY)) return;
-    int *par = parent + (int64_t)b * n;
-    int p = par[i];
-    if (p < 0) return;
-    int x = p, q;
-    while ((q = par[x]) != x) x = q;
-    if (x != p) par[i] = x;
-    const int f = F[(int64_t)b * n + i];
-    if (f != 0) {
-        atomicMax(&hi[(int64_t)b * n + x], f);
-        atomicMax(&nlo[(int64_t)b * n + x], 0x7FFFFFFF - f);
-    }
-}
+// Labels from the roots.  A component that holds two differently labelled pixels cannot be resolved at this level:
+// its root is marked in `bad`, its frame is flagged.
+//   UF_OPTIMISTIC  first level: write out[root] to every unlabelled pixel and look for conflicts in the same pass; the
+//                  rare frames with a conflict are repaired by UF_REPAIR afterwards (labelled == original seed here)
+//   UF_REPAIR      pixels of bad components go back to their seed state, their 64x64 tiles become active
+//   UF_DETECT      second level, pass 1: conflicts only (labelled pixels include first-level results: no repair by
+//   UF_ASSIGN      reset possible), pass 2: label the pixels of the components that are not bad
+enum { UF_OPTIMISTIC = 0, UF_REPAIR = 1, UF_DETECT = 2, UF_ASSIGN = 3 };
 
-__global__ void __launch_bounds__(256) ws_uf_assign_kernel(const int *__restrict__ frame_list, const int *__restrict__ parent, int *__restrict__ F,
-                                                            const uint8_t *__restrict__ active, const int *__restrict__ hi,
-                                                            const int *__restrict__ nlo, int *__restrict__ tie_flags,
-                                                            uint8_t *__restrict__ mark_active, int64_t n, int W, int tilesX,
-                                                            int tilesY)
+template <int MODE>
+__global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict__ frame_list, const int *__restrict__ parent, int *__restrict__ F,
+                                                           const uint8_t *__restrict__ active, uint8_t *__restrict__ bad,
+                                                           const int *__restrict__ markers, const uint8_t *__restrict__ mask,
+                                                           int *__restrict__ tie_flags, uint8_t *__restrict__ mark_active, int64_t n,
+                                                           int W, int tilesX, int tilesY)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = ws_frame(frame_list, blockIdx.y);
     const int r = (int)(i / W), c = (int)(i % W);
     if (i >= n || !ws_active(active, b, r, c, tilesX, tilesY)) return;
-    const int64_t g = (int64_t)b * n + i;
-    int p = parent[g];
-    if (p < 0) return;
-    const int *par = parent + (int64_t)b * n;
-    int x = p, q;
-    while ((q = par[x]) != x) x = q;
-    const int h = hi[(int64_t)b * n + x], l = 0x7FFFFFFF - nlo[(int64_t)b * n + x];
-    const bool bad = h != 0 && h != l;  // two marker ids in one component: not provable at this level
-    if (bad) {
-        if (tie_flags[b] == 0) tie_flags[b] = 1;
-        // the next level only has to revisit the tiles that hold pixels of such components (every other component is
-        // already exactly the reference's basin: its pixels' minimum-key neighbours all lie inside it)
-        if (mark_active) mark_active[((int64_t)b * tilesY + r / WS_T) * tilesX + c / WS_T] = 1;
+    const int64_t fbase = (int64_t)b * n, g = fbase + i;
+    int x = parent[g];
+    if (x < 0) return;
+    const int *par = parent + fbase;
+    int q;
+    while ((q = par[x & (UF_NS - 1)]) != x) x = q;
+    if (x >= UF_NS) return;  // no labelled pixel in the component
+    const int64_t groot = fbase + x;
+    if (MODE == UF_REPAIR) {
+        if (bad[groot]) {
+            F[g] = mask[g] ? markers[g] : 0;
+            if (mark_active) mark_active[((int64_t)b * tilesY + r / WS_T) * tilesX + c / WS_T] = 1;
+        }
+        return;
     }
-    if (F[g] == 0 && !bad) F[g] = h;
+    const int f = F[g];
+    if (MODE == UF_ASSIGN) {
+        if (f == 0 && !bad[groot]) F[g] = F[groot];
+        return;
+    }
+    const int lab = F[groot];  // roots are labelled pixels, never written by this pass
+    if (f == 0) {
+        if (MODE == UF_OPTIMISTIC) F[g] = lab;
+    } else if (f != lab) {
+        bad[groot] = 1;
+        if (tie_flags[b] == 0) tie_flags[b] = 1;
+    }
 }
 
 // (3) proof check: every neighbour whose key equals the minimum neighbour key carries the pixel's label
@@ -451,13 +513,13 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict_
     if (threadIdx.x == 0) *any_changed = 1;
 }
 
-// K64 = (L << 32) | K2 inside the active tiles (and the union-find root slots are cleared there); every other pixel of
+// K64 = (L << 32) | K2 inside the active tiles; every other pixel of
 // a flagged frame gets (L, worst K2): it can sit in the halo of an active tile, where it must never look like a
 // minimum-key neighbour (it is not in the component, so its L is larger than the minimum anyway)
 __global__ void __launch_bounds__(256) ws_pack_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ L, const unsigned *__restrict__ K2,
                                                        const int *__restrict__ frame_flags, const uint8_t *__restrict__ active,
-                                                       unsigned long long *__restrict__ K64, int *__restrict__ hi,
-                                                       int *__restrict__ nlo, int64_t n, int W, int tilesX, int tilesY)
+                                                       unsigned long long *__restrict__ K64, int64_t n, int W, int tilesX,
+                                                       int tilesY)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = ws_frame(frame_list, blockIdx.y);
@@ -465,8 +527,6 @@ __global__ void __launch_bounds__(256) ws_pack_kernel(const int *__restrict__ fr
     const int64_t g = (int64_t)b * n + i;
     if (ws_active(active, b, (int)(i / W), (int)(i % W), tilesX, tilesY)) {
         K64[g] = ((unsigned long long)L[g] << 32) | K2[g];
-        hi[g] = 0;
-        nlo[g] = 0;
     } else {
         K64[g] = ((unsigned long long)L[g] << 32) | 0xFFFFFFFFull;
     }
@@ -735,7 +795,7 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
     if (!check_shape(B, H, W)) return 0;
     size_t n = (size_t)B * H * W;
     int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
-    return 5 * align_up(n * 4) + align_up(n) + 3 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + 3 * align_up(sizeof(int) * B) +
+    return 3 * align_up(n * 4) + 3 * align_up(n) + 3 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + 3 * align_up(sizeof(int) * B) +
            align_up(n * 8) + align_up(n * 4);
 }
 
@@ -765,8 +825,8 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     unsigned long long *heap_key = cv.take<unsigned long long>(n);  // doubles as K64 of the second-level pass
     unsigned *heap_idx = cv.take<unsigned>(n);                      // doubles as K2
     int *uf_parent = cv.take<int>(n);
-    int *uf_hi = cv.take<int>(n);
-    int *uf_nlo = cv.take<int>(n);
+    uint8_t *uf_bad1 = cv.take<uint8_t>(n);  // roots of components the first / second level cannot resolve
+    uint8_t *uf_bad2 = cv.take<uint8_t>(n);
     uint8_t *uf_mask = cv.take<uint8_t>(n);
     if (!cv.ok()) {
         set_error("watershed: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
@@ -818,7 +878,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         // label assignment = union-find over "minimum-key neighbour" links.  A component holding two marker ids flags
         // its frame, stays unlabelled and (first level) marks its tiles active for the next level.
         auto assign_labels = [&](auto *keys, const int *flist, int nframes, const uint8_t *act, int *out_flags,
-                                 uint8_t *mark) -> int {
+                                 bool first_level) -> int {
             using KeyT = std::remove_const_t<std::remove_pointer_t<decltype(keys)>>;
             const dim3 ug(ugrid.x, ugrid.y, nframes), lg(lgrid.x, nframes);
             const int64_t border_px = (int64_t)((H - 1) / UF_TH) * W + (int64_t)((W - 1) / UF_TW) * H;
@@ -831,21 +891,26 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                              tilesX, tilesY);
                 PCSEG_CHECK_LAUNCH();
             }
-            PCSEG_LAUNCH(ws_uf_seed_kernel, lg, dim3(256), 0, s, flist, uf_parent, (const int *)out, act, uf_hi, uf_nlo, npx, W,
-                         tilesX, tilesY);
-            PCSEG_CHECK_LAUNCH();
-            PCSEG_LAUNCH(ws_uf_assign_kernel, lg, dim3(256), 0, s, flist, (const int *)uf_parent, out, act, (const int *)uf_hi,
-                         (const int *)uf_nlo, out_flags, mark, npx, W, tilesX, tilesY);
-            PCSEG_CHECK_LAUNCH();
+            if (first_level) {
+                PCSEG_LAUNCH(ws_uf_label_kernel<UF_OPTIMISTIC>, lg, dim3(256), 0, s, flist, (const int *)uf_parent, out, act,
+                             uf_bad1, markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY);
+                PCSEG_CHECK_LAUNCH();
+            } else {
+                PCSEG_LAUNCH(ws_uf_label_kernel<UF_DETECT>, lg, dim3(256), 0, s, flist, (const int *)uf_parent, out, act, uf_bad2,
+                             markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY);
+                PCSEG_CHECK_LAUNCH();
+                PCSEG_LAUNCH(ws_uf_label_kernel<UF_ASSIGN>, lg, dim3(256), 0, s, flist, (const int *)uf_parent, out, act, uf_bad2,
+                             markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY);
+                PCSEG_CHECK_LAUNCH();
+            }
             return PCSEG_OK;
         };
         uint8_t *active = dirtyB;  // free between the fixed-point loops: which tiles the second level has to revisit
         PCSEG_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * B, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(flags2, 0, sizeof(int) * B, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(active, 0, ntiles, s));
-        PCSEG_CHECK_HIP(hipMemsetAsync(uf_hi, 0, sizeof(int) * n, s));
-        PCSEG_CHECK_HIP(hipMemsetAsync(uf_nlo, 0, sizeof(int) * n, s));
-        rc = assign_labels((const unsigned *)L, (const int *)nullptr, B, (const uint8_t *)nullptr, flags, active);
+        PCSEG_CHECK_HIP(hipMemsetAsync(uf_bad1, 0, n, s));
+        rc = assign_labels((const unsigned *)L, (const int *)nullptr, B, (const uint8_t *)nullptr, flags, true);
         if (rc) return rc;
         if (verify) {
             PCSEG_LAUNCH(ws_check_kernel<unsigned>, pgrid, dim3(256), 0, s, (const unsigned *)L, (const int *)out, markers, mask,
@@ -869,6 +934,11 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             PCSEG_CHECK_HIP(hipMemcpyAsync(frame_list, flagged.data(), sizeof(int) * nfl, hipMemcpyHostToDevice, s));
             PCSEG_CHECK_HIP(hipStreamSynchronize(s));  // `flagged` is pageable host memory
             const dim3 pg2(pgrid.x, pgrid.y, nfl), lg2(lgrid.x, nfl), tg2(tilesX, tilesY, nfl);
+            // the components that hold two marker ids go back to their seeds; their tiles are the second level's work
+            PCSEG_LAUNCH(ws_uf_label_kernel<UF_REPAIR>, lg2, dim3(256), 0, s, (const int *)frame_list, (const int *)uf_parent, out,
+                         (const uint8_t *)nullptr, uf_bad1, markers, mask, flags, active, npx, W, tilesX, tilesY);
+            PCSEG_CHECK_LAUNCH();
+            PCSEG_CHECK_HIP(hipMemsetAsync(uf_bad2, 0, n, s));
             if (verify) {
                 // whole flagged frames, so that the explicit per-pixel check of the second level sees valid keys everywhere
                 PCSEG_LAUNCH(ws_activate_frames_kernel, lg2, dim3(256), 0, s, (const int *)frame_list, (const int *)flags, active,
@@ -886,10 +956,10 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             });
             if (rc) return rc;
             PCSEG_LAUNCH(ws_pack_kernel, lg2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)L, (const unsigned *)K2,
-                         (const int *)flags, (const uint8_t *)active_tiles, K64, uf_hi, uf_nlo, npx, W, tilesX, tilesY);
+                         (const int *)flags, (const uint8_t *)active_tiles, K64, npx, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
             rc = assign_labels((const unsigned long long *)K64, (const int *)frame_list, nfl, (const uint8_t *)active_tiles,
-                               flags2, (uint8_t *)nullptr);
+                               flags2, false);
             if (rc) return rc;
             if (verify) {
                 PCSEG_LAUNCH(ws_check_kernel<unsigned long long>, pgrid, dim3(256), 0, s, (const unsigned long long *)K64,
