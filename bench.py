@@ -195,7 +195,12 @@ def _run(args):
             lib.pcseg_watershed_counters(cnt, 0)
             if cnt[1]:
                 units = 4096.0 * cnt[0] / cnt[1]
-        achieved = bpp * units / avg_s / 1e9
+        launch_bytes = bpp * units
+        if short == "ws_relax_kernel":
+            # one launch per step is the set-up round: it reads the three inputs (9 B/px) and writes value keys, seed
+            # labels and levels (12 B/px) for every pixel instead of the 12 B/px of a plain round
+            launch_bytes += 9.0 * B * H * W * args.steps / dom_calls
+        achieved = launch_bytes / avg_s / 1e9
         total_kernel_ms = sum(ms for _, ms in kernels.values())
         value = world * B * H * W * args.steps / elapsed / 1e6
         traffic = None
@@ -214,6 +219,7 @@ def _run(args):
                        "tie_fallback_frames_last_step": tie_frames, "gathered_roi_rows": n_rois},
             "roofline": {"bound": "hbm", "kernel": dom_name, "launches_per_step": dom_calls / args.steps,
                          "avg_launch_us": round(1e6 * avg_s, 2), "algorithmic_bytes_per_pixel": bpp,
+                         "algorithmic_bytes_per_launch": round(launch_bytes),
                          "pixels_per_launch": round(units),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -120,23 +120,51 @@ __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__res
 // (1) minimax relaxation, tile-local fixed point in LDS.  L and the pixel value share one 64-bit LDS word (x = L,
 // y = value): a sweep step is ONE ds_read_b64 instead of two ds_read_b32 -- the kernel is bound by LDS issue, and the
 // b64 form moves twice the bytes per issue slot (odd pitch: conflict-free for row and column sweeps alike).
-__global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restrict__ val, unsigned *__restrict__ L,
-                                                        const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
-                                                        int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
+// The FIRST round also does the set-up (what ws_init_kernel does for the exact-only mode): value keys, seed levels and
+// the seed labels are computed while the tile is loaded, so the three input arrays are read once and val / L are not
+// written and read back in between.
+struct WsInputs {
+    const float *img;
+    int64_t frame_stride;
+    const int *markers;
+    const uint8_t *mask;
+    int *out;
+};
+
+__global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool FIRST, unsigned *__restrict__ val,
+                                                        unsigned *__restrict__ L, const uint8_t *__restrict__ dirty_in,
+                                                        uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed, int H, int W,
+                                                        int tilesX, int tilesY)
 {
     __shared__ uint2 sLV[WS_N];
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
-    if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
+    if (!FIRST && !dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
     if (threadIdx.x == 0) atomicAdd(any_changed + 1, 1);  // tiles actually processed (measurement: bench.py roofline)
     const int r0 = ty * WS_T, c0 = tx * WS_T;
     const int64_t fbase = (int64_t)b * H * W;
+    // (L, value) of a pixel before any relaxation
+    auto initial = [&](int r, int c) -> uint2 {
+        const int64_t g = fbase + (int64_t)r * W + c;
+        if (!in.mask[g]) return make_uint2(WS_INF, WS_INF);
+        const unsigned v = ws_key(in.img[(int64_t)b * in.frame_stride + (int64_t)r * W + c]);
+        return make_uint2(in.markers[g] != 0 ? v : WS_INF, v);
+    };
     for (int i = threadIdx.x; i < WS_S * WS_S; i += 256) {
         int lr = i / WS_S, lc = i % WS_S;
         int r = r0 + lr - 1, c = c0 + lc - 1;
         uint2 lv = make_uint2(WS_INF, WS_INF);
         if (r >= 0 && r < H && c >= 0 && c < W) {
-            lv.x = L[fbase + (int64_t)r * W + c];
-            lv.y = val[fbase + (int64_t)r * W + c];
+            if (FIRST) {
+                lv = initial(r, c);
+                if (lr >= 1 && lr <= WS_T && lc >= 1 && lc <= WS_T) {  // own pixels: publish value key and seed label
+                    const int64_t g = fbase + (int64_t)r * W + c;
+                    val[g] = lv.y;
+                    in.out[g] = lv.y != WS_INF ? in.markers[g] : 0;
+                }
+            } else {
+                lv.x = L[fbase + (int64_t)r * W + c];
+                lv.y = val[fbase + (int64_t)r * W + c];
+            }
         }
         sLV[lr * WS_P + lc] = lv;
     }
@@ -160,15 +188,15 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restric
         if (!__syncthreads_or(changed)) break;
         changed_any = true;
     }
-    if (!changed_any) return;
+    if (!FIRST && !changed_any) return;
     // mark only the neighbours that share a changed edge (compare with what is still in global memory), then store
-    {
+    if (changed_any) {
         const int e = threadIdx.x >> 6, j = threadIdx.x & 63;
         const int lr = e == 0 ? 1 : (e == 1 ? WS_T : j + 1);
         const int lc = e == 2 ? 1 : (e == 3 ? WS_T : j + 1);
         const int r = r0 + lr - 1, c = c0 + lc - 1;
         bool ch = false;
-        if (r < H && c < W) ch = sLV[lr * WS_P + lc].x != L[fbase + (int64_t)r * W + c];
+        if (r < H && c < W) ch = sLV[lr * WS_P + lc].x != (FIRST ? initial(r, c).x : L[fbase + (int64_t)r * W + c]);
         if (__any(ch) && j == 0) {
             uint8_t *d = dirty_out + (int64_t)b * tilesX * tilesY;
             if (e == 0 && ty > 0) d[(ty - 1) * tilesX + tx] = 1;
@@ -183,7 +211,7 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(const unsigned *__restric
         int r = r0 + lr, c = c0 + lc;
         if (r < H && c < W) L[fbase + (int64_t)r * W + c] = sLV[(lr + 1) * WS_P + lc + 1].x;
     }
-    if (threadIdx.x == 0) *any_changed = 1;
+    if (changed_any && threadIdx.x == 0) *any_changed = 1;
 }
 
 // kernels of the second level are launched over the flagged frames only: grid index -> frame id through a list
@@ -860,15 +888,18 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     };
     PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int) * 16, s));
     long long relax_launches = 0;
-    PCSEG_LAUNCH(ws_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, frame_stride, markers, mask, val, L,
-                       out, (int64_t)H * W, (int64_t)n);
-    PCSEG_CHECK_LAUNCH();
     if (mode == 1) {
+        PCSEG_LAUNCH(ws_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, frame_stride, markers, mask, val, L,
+                     out, (int64_t)H * W, (int64_t)n);
+        PCSEG_CHECK_LAUNCH();
         PCSEG_LAUNCH(ws_set_flags_kernel, dim3((B + 63) / 64), dim3(64), 0, s, flags2, B, 1);
         PCSEG_CHECK_LAUNCH();
     } else {
+        const WsInputs inputs{img, frame_stride, markers, mask, out};
         int rc = iterate(nullptr, [&](uint8_t *din, uint8_t *dout) {
-            PCSEG_LAUNCH(ws_relax_kernel, tgrid, dim3(256), 0, s, val, L, din, dout, changed, H, W, tilesX, tilesY);
+            // round 0 doubles as the set-up pass; tiles read their halo from the inputs there, never from L
+            PCSEG_LAUNCH(ws_relax_kernel, tgrid, dim3(256), 0, s, inputs, relax_launches == 0, val, L, din, dout, changed, H, W,
+                         tilesX, tilesY);
             ++relax_launches;
         });
         if (rc) return rc;
