@@ -131,16 +131,30 @@ struct WsInputs {
     int *out;
 };
 
+//
+// Rounds ALTERNATE between two tilings: tile (tx, ty) starts at (ty * 64 - off, tx * 64 - off) with off = 0 in even
+// rounds and 32 in odd ones, so the tile borders of one round are tile centres of the next and a path that winds
+// across a border is resolved inside one tile a round later instead of costing a round per crossing.  Which tiles the
+// next round has to visit follows from the half edges that changed: after a tile reached its fixed point its cells are
+// consistent with each other, a violated pixel can only sit on the tile's rim next to a neighbour outside, and rim
+// cell plus outside neighbour both lie in the ONE tile of the other tiling that is centred on the nearest tile
+// corner.  So each tile marks, per corner quadrant, that corner's tile if one of the quadrant's two outer half
+// edges changed.  (grid = this round's tiling, dirty_in in its layout; dirty_out in the other tiling's layout.)
+struct WsTiling {
+    int off;     // 0 or WS_T / 2
+    int nx, ny;  // tiles per frame in x and y
+};
+
 __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool FIRST, unsigned *__restrict__ val,
                                                         unsigned *__restrict__ L, const uint8_t *__restrict__ dirty_in,
                                                         uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed, int H, int W,
-                                                        int tilesX, int tilesY)
+                                                        WsTiling cur, WsTiling nxt)
 {
     __shared__ uint2 sLV[WS_N];
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
-    if (!FIRST && !dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
+    if (!FIRST && !dirty_in[((int64_t)b * cur.ny + ty) * cur.nx + tx]) return;
     if (threadIdx.x == 0) atomicAdd(any_changed + 1, 1);  // tiles actually processed (measurement: bench.py roofline)
-    const int r0 = ty * WS_T, c0 = tx * WS_T;
+    const int r0 = ty * WS_T - cur.off, c0 = tx * WS_T - cur.off;
     const int64_t fbase = (int64_t)b * H * W;
     // (L, value) of a pixel before any relaxation
     auto initial = [&](int r, int c) -> uint2 {
@@ -189,27 +203,30 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
         changed_any = true;
     }
     if (!FIRST && !changed_any) return;
-    // mark only the neighbours that share a changed edge (compare with what is still in global memory), then store
+    // half edges that changed (compare with what is still in global memory) -> tiles of the next round; then store
     if (changed_any) {
-        const int e = threadIdx.x >> 6, j = threadIdx.x & 63;
-        const int lr = e == 0 ? 1 : (e == 1 ? WS_T : j + 1);
-        const int lc = e == 2 ? 1 : (e == 3 ? WS_T : j + 1);
+        // thread = (half edge e, cell j): e 0..3 horizontal (top-left, top-right, bottom-left, bottom-right), e 4..7
+        // vertical (left-top, left-bottom, right-top, right-bottom); each half edge is one half wave
+        const int e = threadIdx.x >> 5, j = threadIdx.x & 31;
+        const int qy = e < 4 ? (e >> 1) : (e & 1), qx = e < 4 ? (e & 1) : ((e >> 1) & 1);
+        const int lr = e < 4 ? (qy ? WS_T : 1) : qy * (WS_T / 2) + j + 1;
+        const int lc = e < 4 ? qx * (WS_T / 2) + j + 1 : (qx ? WS_T : 1);
         const int r = r0 + lr - 1, c = c0 + lc - 1;
         bool ch = false;
-        if (r < H && c < W) ch = sLV[lr * WS_P + lc].x != (FIRST ? initial(r, c).x : L[fbase + (int64_t)r * W + c]);
-        if (__any(ch) && j == 0) {
-            uint8_t *d = dirty_out + (int64_t)b * tilesX * tilesY;
-            if (e == 0 && ty > 0) d[(ty - 1) * tilesX + tx] = 1;
-            if (e == 1 && ty + 1 < tilesY) d[(ty + 1) * tilesX + tx] = 1;
-            if (e == 2 && tx > 0) d[ty * tilesX + tx - 1] = 1;
-            if (e == 3 && tx + 1 < tilesX) d[ty * tilesX + tx + 1] = 1;
+        if (r >= 0 && r < H && c >= 0 && c < W)
+            ch = sLV[lr * WS_P + lc].x != (FIRST ? initial(r, c).x : L[fbase + (int64_t)r * W + c]);
+        const unsigned long long half = (threadIdx.x & 32) ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+        if ((__ballot(ch) & half) && j == 0) {
+            // the tile of the other tiling that holds this corner quadrant (rows r0 + qy * 32 .., cols c0 + qx * 32 ..)
+            const int oy = (r0 + qy * (WS_T / 2) + nxt.off) / WS_T, ox = (c0 + qx * (WS_T / 2) + nxt.off) / WS_T;
+            if (oy >= 0 && oy < nxt.ny && ox >= 0 && ox < nxt.nx) dirty_out[((int64_t)b * nxt.ny + oy) * nxt.nx + ox] = 1;
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < WS_T * WS_T; i += 256) {
         int lr = i / WS_T, lc = i % WS_T;
         int r = r0 + lr, c = c0 + lc;
-        if (r < H && c < W) L[fbase + (int64_t)r * W + c] = sLV[(lr + 1) * WS_P + lc + 1].x;
+        if (r >= 0 && r < H && c >= 0 && c < W) L[fbase + (int64_t)r * W + c] = sLV[(lr + 1) * WS_P + lc + 1].x;
     }
     if (changed_any && threadIdx.x == 0) *any_changed = 1;
 }
@@ -823,7 +840,7 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
     if (!check_shape(B, H, W)) return 0;
     size_t n = (size_t)B * H * W;
     int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
-    return 3 * align_up(n * 4) + 3 * align_up(n) + 3 * align_up((size_t)B * tilesX * tilesY) + align_up(64) + 3 * align_up(sizeof(int) * B) +
+    return 3 * align_up(n * 4) + 3 * align_up(n) + 2 * align_up((size_t)B * (tilesX + 1) * (tilesY + 1)) + align_up((size_t)B * tilesX * tilesY) + align_up(64) + 3 * align_up(sizeof(int) * B) +
            align_up(n * 8) + align_up(n * 4);
 }
 
@@ -840,11 +857,12 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     const size_t n = (size_t)B * H * W;
     const int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
     const size_t ntiles = (size_t)B * tilesX * tilesY;
+    const size_t ntiles_max = (size_t)B * (tilesX + 1) * (tilesY + 1);  // the half-tile-shifted tiling has one more per axis
     Carver cv(workspace, workspace_bytes);
     unsigned *val = cv.take<unsigned>(n);
     unsigned *L = cv.take<unsigned>(n);
-    uint8_t *dirtyA = cv.take<uint8_t>(ntiles);
-    uint8_t *dirtyB = cv.take<uint8_t>(ntiles);
+    uint8_t *dirtyA = cv.take<uint8_t>(ntiles_max);
+    uint8_t *dirtyB = cv.take<uint8_t>(ntiles_max);
     uint8_t *active_tiles = cv.take<uint8_t>(ntiles);
     int *changed = cv.take<int>(16);
     int *flags = cv.take<int>(B);
@@ -896,12 +914,32 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         PCSEG_CHECK_LAUNCH();
     } else {
         const WsInputs inputs{img, frame_stride, markers, mask, out};
-        int rc = iterate(nullptr, [&](uint8_t *din, uint8_t *dout) {
-            // round 0 doubles as the set-up pass; tiles read their halo from the inputs there, never from L
-            PCSEG_LAUNCH(ws_relax_kernel, tgrid, dim3(256), 0, s, inputs, relax_launches == 0, val, L, din, dout, changed, H, W,
-                         tilesX, tilesY);
-            ++relax_launches;
-        });
+        // minimax relaxation: host-driven rounds over alternating tilings, polled every 4 rounds
+        const WsTiling tilings[2] = {{0, tilesX, tilesY}, {WS_T / 2, (W + WS_T / 2 + WS_T - 1) / WS_T, (H + WS_T / 2 + WS_T - 1) / WS_T}};
+        int rc = PCSEG_OK;
+        {
+            uint8_t *din = dirtyA, *dout = dirtyB;
+            for (int round = 0;; round += 4) {
+                PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int), s));
+                for (int k = 0; k < 4; ++k) {
+                    const WsTiling &cur = tilings[(round + k) & 1], &nxt = tilings[(round + k + 1) & 1];
+                    PCSEG_CHECK_HIP(hipMemsetAsync(dout, 0, ntiles_max, s));
+                    PCSEG_LAUNCH(ws_relax_kernel, dim3(cur.nx, cur.ny, B), dim3(256), 0, s, inputs, round + k == 0, val, L,
+                                 (const uint8_t *)din, dout, changed, H, W, cur, nxt);
+                    PCSEG_CHECK_LAUNCH();
+                    ++relax_launches;
+                    uint8_t *t = din; din = dout; dout = t;
+                }
+                int host_changed = 0;
+                PCSEG_CHECK_HIP(hipMemcpyAsync(&host_changed, changed, sizeof(int), hipMemcpyDeviceToHost, s));
+                PCSEG_CHECK_HIP(hipStreamSynchronize(s));
+                if (!host_changed) break;
+                if (round > 4 * (tilesX * tilesY + 64) * 64) {
+                    set_error("watershed: fixed point did not converge");
+                    return PCSEG_ERR_HIP;
+                }
+            }
+        }
         if (rc) return rc;
         const dim3 ugrid((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B);
         const dim3 lgrid((unsigned)(((size_t)H * W + 255) / 256), B);
