@@ -147,8 +147,8 @@ struct WsTiling {
 
 __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool FIRST, unsigned *__restrict__ val,
                                                         unsigned *__restrict__ L, const uint8_t *__restrict__ dirty_in,
-                                                        uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed, int H, int W,
-                                                        WsTiling cur, WsTiling nxt)
+                                                        uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed,
+                                                        int *__restrict__ any_marked, int H, int W, WsTiling cur, WsTiling nxt)
 {
     __shared__ uint2 sLV[WS_N];
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
@@ -219,7 +219,10 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
         if ((__ballot(ch) & half) && j == 0) {
             // the tile of the other tiling that holds this corner quadrant (rows r0 + qy * 32 .., cols c0 + qx * 32 ..)
             const int oy = (r0 + qy * (WS_T / 2) + nxt.off) / WS_T, ox = (c0 + qx * (WS_T / 2) + nxt.off) / WS_T;
-            if (oy >= 0 && oy < nxt.ny && ox >= 0 && ox < nxt.nx) dirty_out[((int64_t)b * nxt.ny + oy) * nxt.nx + ox] = 1;
+            if (oy >= 0 && oy < nxt.ny && ox >= 0 && ox < nxt.nx) {
+                dirty_out[((int64_t)b * nxt.ny + oy) * nxt.nx + ox] = 1;
+                *any_marked = 1;  // the next round has work
+            }
         }
     }
     __syncthreads();
@@ -918,23 +921,26 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         const WsTiling tilings[2] = {{0, tilesX, tilesY}, {WS_T / 2, (W + WS_T / 2 + WS_T - 1) / WS_T, (H + WS_T / 2 + WS_T - 1) / WS_T}};
         int rc = PCSEG_OK;
         {
+            // polled after 8 rounds, then after every 2: the fixed point is reached when a round marks no tile for the
+            // next one (changed[2] belongs to the last round of a window, changed[3] collects the others')
             uint8_t *din = dirtyA, *dout = dirtyB;
-            for (int round = 0;; round += 4) {
-                PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int), s));
-                for (int k = 0; k < 4; ++k) {
-                    const WsTiling &cur = tilings[(round + k) & 1], &nxt = tilings[(round + k + 1) & 1];
+            for (int round = 0;;) {
+                const int window = round == 0 ? 8 : 2;
+                PCSEG_CHECK_HIP(hipMemsetAsync(changed + 2, 0, sizeof(int), s));
+                for (int k = 0; k < window; ++k, ++round) {
+                    const WsTiling &cur = tilings[round & 1], &nxt = tilings[(round + 1) & 1];
                     PCSEG_CHECK_HIP(hipMemsetAsync(dout, 0, ntiles_max, s));
-                    PCSEG_LAUNCH(ws_relax_kernel, dim3(cur.nx, cur.ny, B), dim3(256), 0, s, inputs, round + k == 0, val, L,
-                                 (const uint8_t *)din, dout, changed, H, W, cur, nxt);
+                    PCSEG_LAUNCH(ws_relax_kernel, dim3(cur.nx, cur.ny, B), dim3(256), 0, s, inputs, round == 0, val, L,
+                                 (const uint8_t *)din, dout, changed, changed + (k == window - 1 ? 2 : 3), H, W, cur, nxt);
                     PCSEG_CHECK_LAUNCH();
                     ++relax_launches;
                     uint8_t *t = din; din = dout; dout = t;
                 }
-                int host_changed = 0;
-                PCSEG_CHECK_HIP(hipMemcpyAsync(&host_changed, changed, sizeof(int), hipMemcpyDeviceToHost, s));
+                int last_marked = 0;
+                PCSEG_CHECK_HIP(hipMemcpyAsync(&last_marked, changed + 2, sizeof(int), hipMemcpyDeviceToHost, s));
                 PCSEG_CHECK_HIP(hipStreamSynchronize(s));
-                if (!host_changed) break;
-                if (round > 4 * (tilesX * tilesY + 64) * 64) {
+                if (!last_marked) break;
+                if (round > (tilesX * tilesY + 64) * 64) {
                     set_error("watershed: fixed point did not converge");
                     return PCSEG_ERR_HIP;
                 }
