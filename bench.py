@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = 2 per core)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event table to stderr")
+    ap.add_argument("--serial", action="store_true",
+                    help="profiling aid, not the headline: both kernel chains on one stream, so that per-kernel durations "
+                         "are not inflated by the other chain's kernels sharing the CUs")
     ap.add_argument("--levels", type=int, default=0,
                     help="NOT the headline workload: quantise the boundary plane to k/LEVELS (random-forest-like vote "
                          "fractions); every frame then floods through ties and takes the watershed's exact path")
@@ -135,7 +138,7 @@ def _run(args):
     stack = synth.gen_batch_torch(10_000 + rank * B, B, H, W, dev)
     if args.levels > 0:
         stack[:, 3] = torch.round(stack[:, 3] * args.levels) / args.levels
-    pipe = FramePipeline(dict(synth.CELL_TYPES_5))
+    pipe = FramePipeline(dict(synth.CELL_TYPES_5), overlap=not args.serial)
     res = None
     # setup (not warmup): two priming passes so that torch's caching allocator holds every workspace block before the
     # W untimed warmup steps and the K timed steps

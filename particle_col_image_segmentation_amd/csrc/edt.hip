@@ -42,48 +42,47 @@ struct FgNotInSetU8 {
     }
 };
 
-// one thread per (word, column): fg bits of 32 rows; any_bg[b] |= (some pixel is not fg)
+// one thread per (word, column): fg bits of 32 rows
 template <typename Fg>
-__global__ void __launch_bounds__(256) edt_bits_kernel(Fg fg, unsigned *__restrict__ bits, int *__restrict__ any_bg, int H, int W, int nch)
+__global__ void __launch_bounds__(256) edt_bits_kernel(Fg fg, unsigned *__restrict__ bits, int H, int W, int nch)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int ch = blockIdx.y, b = blockIdx.z;
     if (c >= W) return;
     const int64_t n = (int64_t)H * W;
     const int r0 = ch * EDT_CH;
-    unsigned word = 0, valid = 0;
+    unsigned word = 0;
 #pragma unroll 8
     for (int j = 0; j < EDT_CH; ++j) {
         int r = r0 + j;
-        if (r < H) {
-            valid |= 1u << j;
-            if (fg(b, (int64_t)r * W + c, n)) word |= 1u << j;
-        }
+        if (r < H && fg(b, (int64_t)r * W + c, n)) word |= 1u << j;
     }
     bits[((int64_t)b * nch + ch) * W + c] = word;
-    if ((word & valid) != valid && any_bg[b] == 0) any_bg[b] = 1;
 }
 
 // per column: distance from the first row of each word to the nearest zero above it (up),
 // and from the last row of each word to the nearest zero below it (dn); G_INF if none.
+// any_bg[b] = 1 if the frame has a zero pixel at all: one plain store per block (a flag that every thread of the bit
+// pass touches would make all of them queue on one cache line).
 __global__ void __launch_bounds__(256) edt_carry_kernel(const unsigned *__restrict__ bits, uint16_t *__restrict__ up,
-                                                         uint16_t *__restrict__ dn, int H, int W, int nch)
+                                                         uint16_t *__restrict__ dn, int *__restrict__ any_bg, int H, int W, int nch)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
-    if (c >= W) return;
     const int64_t base = (int64_t)b * nch * W + c;
+    bool has_zero = false;
     unsigned d = G_INF;  // distance from row (r0 - 1) ... tracked as "distance of first row of the word to the zero"
-    for (int ch = 0; ch < nch; ++ch) {
+    for (int ch = 0; c < W && ch < nch; ++ch) {
         up[base + (int64_t)ch * W] = (uint16_t)d;
         int rows = min(EDT_CH, H - ch * EDT_CH);
         unsigned valid = rows == 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
         unsigned zero = ~bits[base + (int64_t)ch * W] & valid;
-        if (zero) d = rows - (31 - __clz(zero));  // from first row of next word to the last zero of this word
+        if (zero) { d = rows - (31 - __clz(zero)); has_zero = true; }  // from first row of next word to the last zero of this word
         else d = d == G_INF ? G_INF : d + rows;
     }
+    if (__syncthreads_or(has_zero) && threadIdx.x == 0) any_bg[b] = 1;
     d = G_INF;
-    for (int ch = nch - 1; ch >= 0; --ch) {
+    for (int ch = nch - 1; c < W && ch >= 0; --ch) {
         dn[base + (int64_t)ch * W] = (uint16_t)d;
         int rows = min(EDT_CH, H - ch * EDT_CH);
         unsigned valid = rows == 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
@@ -107,10 +106,10 @@ __device__ __forceinline__ unsigned vdist(unsigned word, unsigned valid, int j, 
 
 // ---- epilogues of the horizontal pass
 struct EpiD2 {
+    static constexpr bool kThreshold = false;
     int *d2;
     int cap;  // < 0: exact
     __device__ __forceinline__ int kmax(int W) const { return cap < 0 ? W : (int)sqrtf((float)cap) + 1; }
-    __device__ __forceinline__ bool wants(int64_t) const { return true; }
     __device__ __forceinline__ void store(int64_t i, long long v, bool any_bg, int r, int c, unsigned long long &cnt) const
     {
         if (!any_bg) v = (long long)(r + 1) * (r + 1) + (long long)c * c;  // scipy: virtual zero pixel at (-1, 0)
@@ -118,28 +117,29 @@ struct EpiD2 {
         d2[i] = (int)v;
     }
 };
+// threshold epilogues only need "is there a zero pixel within sqrt(R2)": they run on edt_reach_kernel
 struct EpiDilate {
+    static constexpr bool kThreshold = true;
     uint8_t *out;
     int r2;
-    __device__ __forceinline__ int kmax(int) const { return (int)sqrtf((float)r2) + 1; }
-    __device__ __forceinline__ bool wants(int64_t) const { return true; }
-    __device__ __forceinline__ void store(int64_t i, long long v, bool any_bg, int, int, unsigned long long &) const
+    __device__ __forceinline__ int R2() const { return r2; }
+    __device__ __forceinline__ void store(int64_t i, bool within, bool any_bg, int, int, unsigned long long &) const
     {
-        out[i] = (any_bg && v <= r2) ? 1 : 0;  // empty set dilates to the empty set
+        out[i] = (any_bg && within) ? 1 : 0;  // empty set dilates to the empty set
     }
 };
 struct EpiFillParticle {
+    static constexpr bool kThreshold = true;
     const uint8_t *ds;
     uint8_t *out;
     int cell_label, overlap_label, r2, thr2;  // overlap if d2 <= r2 (dilation) or d2 < thr2 (distance)
-    __device__ __forceinline__ int kmax(int) const { return (int)sqrtf((float)max(r2, thr2)) + 1; }
-    __device__ __forceinline__ bool wants(int64_t i) const { return ds[i] == cell_label; }
-    __device__ __forceinline__ void store(int64_t i, long long v, bool any_bg, int r, int c, unsigned long long &cnt) const
+    __device__ __forceinline__ int R2() const { return max(r2, thr2 - 1); }
+    __device__ __forceinline__ void store(int64_t i, bool within, bool any_bg, int r, int c, unsigned long long &cnt) const
     {
         uint8_t z = ds[i];
         if (z == cell_label) {
             bool ov;
-            if (any_bg) ov = (v <= r2) || (v < thr2);
+            if (any_bg) ov = within;
             else ov = ((long long)(r + 1) * (r + 1) + (long long)c * c) < thr2;  // only the EDT term sees the virtual pixel
             if (ov) { z = (uint8_t)overlap_label; ++cnt; }
         }
@@ -178,9 +178,7 @@ __global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict
         const uint16_t *gr = g + j * W;
         // 32-bit arithmetic is exact here: g <= 32767 and k < 32768, so g*g + k*k < 2^31
         unsigned best;
-        if (!epi.wants(gi)) {
-            best = 0;
-        } else {
+        {
             unsigned g0 = gr[c];
             best = g0 == G_INF ? 0xFFFFFFFFu : g0 * g0;
             // four offsets per trip: the 8 LDS reads are issued together; offsets past the exit point are still true
@@ -209,10 +207,106 @@ __global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict
     }
 }
 
+// Horizontal pass of the threshold epilogues.  "Some zero pixel within distance sqrt(R2)" means: some column c' of the
+// row with vertical distance g(c') and g^2 + (c - c')^2 <= R2, i.e. c lies in [c' - w, c' + w] with
+// w = floor(sqrt(R2 - g^2)).  The union of those intervals is one prefix maximum of (c' + w) from the left and one
+// suffix minimum of (c' - w) from the right: O(1) per pixel instead of a search over up to 2 sqrt(R2) + 1 columns.
+// A wave owns two of the block's 8 rows and walks them in 64-column chunks (lane = column: conflict-free LDS,
+// coalesced stores); the left-pass verdict rides in bit 15 of the staged distance.
+__device__ __forceinline__ int reach_halfwidth(unsigned g, int R2)
+{
+    const int t = R2 - (int)(g * g);  // caller guarantees g * g <= R2
+    int w = (int)__fsqrt_rn((float)t);
+    if (w * w > t) --w;
+    else if ((w + 1) * (w + 1) <= t) ++w;
+    return w;
+}
+
+template <typename Epi>
+__global__ void __launch_bounds__(256) edt_reach_kernel(const unsigned *__restrict__ bits, const uint16_t *__restrict__ up,
+                                                         const uint16_t *__restrict__ dn, const int *__restrict__ any_bg,
+                                                         Epi epi, unsigned long long *__restrict__ count, int H, int W, int nch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t g[];  // [EDT_RB][W]
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * EDT_RB;
+    const int ch = r0 / EDT_CH, j0 = r0 % EDT_CH;
+    const int rows_in_word = min(EDT_CH, H - ch * EDT_CH);
+    const unsigned valid = rows_in_word == 32 ? 0xFFFFFFFFu : ((1u << rows_in_word) - 1u);
+    const int nrows = min(EDT_RB, H - r0);
+    const int64_t wbase = ((int64_t)b * nch + ch) * W;
+    for (int c = threadIdx.x; c < W; c += 256) {
+        unsigned word = bits[wbase + c];
+        unsigned u = up[wbase + c], d = dn[wbase + c];
+#pragma unroll
+        for (int j = 0; j < EDT_RB; ++j)
+            if (j < nrows) g[j * W + c] = (uint16_t)min(vdist(word, valid, j0 + j, u, d, rows_in_word), 0x7FFFu);  // bit 15 stays free
+    }
+    __syncthreads();
+    const bool anybg = any_bg[b] != 0;
+    const int R2 = epi.R2();
+    const unsigned gmax = (unsigned)sqrtf((float)R2) + 1;  // larger distances can never be within reach
+    const int64_t fbase = (int64_t)b * H * W;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int nchunks = (W + WAVE - 1) / WAVE;
+    unsigned long long cnt = 0;
+    for (int j = wave; j < nrows; j += 4) {
+        uint16_t *gr = g + j * W;
+        int carry = -1;
+        for (int k = 0; k < nchunks; ++k) {  // left to right: furthest column reached by the intervals that start at or before c
+            const int c = k * WAVE + lane;
+            const unsigned gv = c < W ? gr[c] : 0x7FFFu;
+            int x = (gv <= gmax && (int)(gv * gv) <= R2) ? c + reach_halfwidth(gv, R2) : -1;
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const int t = __shfl_up(x, off);
+                if (lane >= off) x = max(x, t);
+            }
+            x = max(x, carry);
+            carry = __shfl(x, WAVE - 1);
+            if (c < W && x >= c) gr[c] = (uint16_t)(gv | 0x8000u);
+        }
+        carry = 0x7FFFFFFF;
+        for (int k = nchunks - 1; k >= 0; --k) {  // right to left, then the verdict
+            const int c = k * WAVE + lane;
+            const unsigned raw = c < W ? gr[c] : 0x7FFFu;
+            const unsigned gv = raw & 0x7FFFu;
+            int x = (gv <= gmax && (int)(gv * gv) <= R2) ? c - reach_halfwidth(gv, R2) : 0x7FFFFFFF;
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const int t = __shfl_down(x, off);
+                if (lane + off < WAVE) x = min(x, t);
+            }
+            x = min(x, carry);
+            carry = __shfl(x, 0);
+            if (c < W) epi.store(fbase + (int64_t)(r0 + j) * W + c, (raw & 0x8000u) != 0 || x <= c, anybg, r0 + j, c, cnt);
+        }
+    }
+    if (count) {  // per-block partial (plain store): block_counts[b][blockIdx.x], summed by edt_count_kernel
+        __shared__ unsigned long long wsum[4];
+        for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (lane == 0) wsum[wave] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) count[(int64_t)b * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+}
+
+// count[b] += sum of the frame's block partials (one wave per frame)
+__global__ void __launch_bounds__(64) edt_count_kernel(const unsigned long long *__restrict__ block_counts, int nblocks,
+                                                        unsigned long long *__restrict__ count)
+{
+    const int b = blockIdx.x;
+    unsigned long long s = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 64) s += block_counts[(int64_t)b * nblocks + i];
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) count[b] += s;
+}
+
 struct EdtWs {
     unsigned *bits;
     uint16_t *up, *dn;
     int *any_bg;
+    unsigned long long *block_counts;  // [B][ceil(H / EDT_RB)] partial counts of the threshold epilogues
     int nch;
 };
 
@@ -220,7 +314,8 @@ static size_t edt_ws_bytes(int B, int H, int W)
 {
     int nch = (H + EDT_CH - 1) / EDT_CH;
     size_t words = (size_t)B * nch * W;
-    return align_up(words * 4) + 2 * align_up(words * 2) + align_up(sizeof(int) * B);
+    return align_up(words * 4) + 2 * align_up(words * 2) + align_up(sizeof(int) * B) +
+           align_up(sizeof(unsigned long long) * B * ((H + EDT_RB - 1) / EDT_RB));
 }
 
 static EdtWs edt_carve(Carver &cv, int B, int H, int W)
@@ -232,6 +327,7 @@ static EdtWs edt_carve(Carver &cv, int B, int H, int W)
     ws.up = cv.take<uint16_t>(words);
     ws.dn = cv.take<uint16_t>(words);
     ws.any_bg = cv.take<int>(B);
+    ws.block_counts = cv.take<unsigned long long>((size_t)B * ((H + EDT_RB - 1) / EDT_RB));
     return ws;
 }
 
@@ -252,14 +348,25 @@ static int edt_run(Fg fg, Epi epi, unsigned long long *count, int B, int H, int 
     }
     PCSEG_CHECK_HIP(hipMemsetAsync(ws.any_bg, 0, sizeof(int) * B, s));
     dim3 g1((W + 255) / 256, ws.nch, B);
-    PCSEG_LAUNCH((edt_bits_kernel<Fg>), g1, dim3(256), 0, s, fg, ws.bits, ws.any_bg, H, W, ws.nch);
+    PCSEG_LAUNCH((edt_bits_kernel<Fg>), g1, dim3(256), 0, s, fg, ws.bits, H, W, ws.nch);
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(edt_carry_kernel, dim3((W + 255) / 256, B), dim3(256), 0, s, ws.bits, ws.up, ws.dn, H, W, ws.nch);
+    PCSEG_LAUNCH(edt_carry_kernel, dim3((W + 255) / 256, B), dim3(256), 0, s, ws.bits, ws.up, ws.dn, ws.any_bg, H, W, ws.nch);
     PCSEG_CHECK_LAUNCH();
-    if (lds > 64 * 1024)
-        PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)edt_row_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 g2((H + EDT_RB - 1) / EDT_RB, B);
-    PCSEG_LAUNCH((edt_row_kernel<Epi>), g2, dim3(256), lds, s, ws.bits, ws.up, ws.dn, ws.any_bg, epi, count, H, W, ws.nch);
+    if constexpr (Epi::kThreshold) {
+        if (lds > 64 * 1024)
+            PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)edt_reach_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PCSEG_LAUNCH((edt_reach_kernel<Epi>), g2, dim3(256), lds, s, ws.bits, ws.up, ws.dn, ws.any_bg, epi,
+                     count ? ws.block_counts : nullptr, H, W, ws.nch);
+        if (count) {
+            PCSEG_CHECK_LAUNCH();
+            PCSEG_LAUNCH(edt_count_kernel, dim3(B), dim3(64), 0, s, (const unsigned long long *)ws.block_counts, (int)g2.x, count);
+        }
+    } else {
+        if (lds > 64 * 1024)
+            PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)edt_row_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PCSEG_LAUNCH((edt_row_kernel<Epi>), g2, dim3(256), lds, s, ws.bits, ws.up, ws.dn, ws.any_bg, epi, count, H, W, ws.nch);
+    }
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

@@ -32,6 +32,7 @@ constexpr int WS_S = WS_T + 2;     // with halo
 constexpr int WS_P = 67;           // LDS row pitch in elements (odd: row-per-lane sweeps are bank-conflict free)
 constexpr int WS_N = WS_S * WS_P;  // LDS elements per tile array
 constexpr unsigned WS_INF = 0xFFFFFFFFu;
+constexpr int WS_CNT0 = 32, WS_CNT_STRIDE = 32, WS_CHANGED_INTS = WS_CNT0 + 16 * WS_CNT_STRIDE;  // layout of the `changed` block
 
 // order-preserving key of a float32 (the reference compares float64(image)); -0.0 == +0.0
 __device__ __forceinline__ unsigned ws_key(float f)
@@ -153,7 +154,9 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
     __shared__ uint2 sLV[WS_N];
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
     if (!FIRST && !dirty_in[((int64_t)b * cur.ny + ty) * cur.nx + tx]) return;
-    if (threadIdx.x == 0) atomicAdd(any_changed + 1, 1);  // tiles actually processed (measurement: bench.py roofline)
+    // tiles actually processed (measurement: bench.py roofline), spread over 16 cache lines: one counter would make
+    // every block of the launch queue on the same line
+    if (threadIdx.x == 0) atomicAdd(any_changed + WS_CNT0 + WS_CNT_STRIDE * ((tx + 5 * ty + 3 * b) & 15), 1);
     const int r0 = ty * WS_T - cur.off, c0 = tx * WS_T - cur.off;
     const int64_t fbase = (int64_t)b * H * W;
     // (L, value) of a pixel before any relaxation
@@ -221,7 +224,7 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
             const int oy = (r0 + qy * (WS_T / 2) + nxt.off) / WS_T, ox = (c0 + qx * (WS_T / 2) + nxt.off) / WS_T;
             if (oy >= 0 && oy < nxt.ny && ox >= 0 && ox < nxt.nx) {
                 dirty_out[((int64_t)b * nxt.ny + oy) * nxt.nx + ox] = 1;
-                *any_marked = 1;  // the next round has work
+                if (*any_marked == 0) *any_marked = 1;  // the next round has work (read first: most blocks find it set)
             }
         }
     }
@@ -231,7 +234,7 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
         int r = r0 + lr, c = c0 + lc;
         if (r >= 0 && r < H && c >= 0 && c < W) L[fbase + (int64_t)r * W + c] = sLV[(lr + 1) * WS_P + lc + 1].x;
     }
-    if (changed_any && threadIdx.x == 0) *any_changed = 1;
+    if (changed_any && threadIdx.x == 0 && *any_changed == 0) *any_changed = 1;
 }
 
 // kernels of the second level are launched over the flagged frames only: grid index -> frame id through a list
@@ -843,7 +846,7 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
     if (!check_shape(B, H, W)) return 0;
     size_t n = (size_t)B * H * W;
     int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
-    return 3 * align_up(n * 4) + 3 * align_up(n) + 2 * align_up((size_t)B * (tilesX + 1) * (tilesY + 1)) + align_up((size_t)B * tilesX * tilesY) + align_up(64) + 3 * align_up(sizeof(int) * B) +
+    return 3 * align_up(n * 4) + 3 * align_up(n) + 2 * align_up((size_t)B * (tilesX + 1) * (tilesY + 1)) + align_up((size_t)B * tilesX * tilesY) + align_up(sizeof(int) * WS_CHANGED_INTS) + 3 * align_up(sizeof(int) * B) +
            align_up(n * 8) + align_up(n * 4);
 }
 
@@ -867,7 +870,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     uint8_t *dirtyA = cv.take<uint8_t>(ntiles_max);
     uint8_t *dirtyB = cv.take<uint8_t>(ntiles_max);
     uint8_t *active_tiles = cv.take<uint8_t>(ntiles);
-    int *changed = cv.take<int>(16);
+    int *changed = cv.take<int>(WS_CHANGED_INTS);  // [0] any change, [2]/[3] marks, [WS_CNT0 + 32 i] tile counters
     int *flags = cv.take<int>(B);
     int *flags2 = cv.take<int>(B);
     int *frame_list = cv.take<int>(B);
@@ -907,7 +910,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             }
         }
     };
-    PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int) * 16, s));
+    PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int) * WS_CHANGED_INTS, s));
     long long relax_launches = 0;
     if (mode == 1) {
         PCSEG_LAUNCH(ws_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, frame_stride, markers, mask, val, L,
@@ -1048,10 +1051,10 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         PCSEG_LAUNCH(ws_exact_kernel, dim3(B), dim3(256), 0, s, val, markers, mask, out, flags2, heap_key, heap_idx, H, W);
         PCSEG_CHECK_LAUNCH();
     }
-    int host_counts[2] = {0, 0};
-    PCSEG_CHECK_HIP(hipMemcpyAsync(host_counts, changed, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+    int host_counts[WS_CHANGED_INTS];
+    PCSEG_CHECK_HIP(hipMemcpyAsync(host_counts, changed, sizeof(int) * WS_CHANGED_INTS, hipMemcpyDeviceToHost, s));
     PCSEG_CHECK_HIP(hipStreamSynchronize(s));
-    g_ws_counters[0] += host_counts[1];
+    for (int i = 0; i < 16; ++i) g_ws_counters[0] += host_counts[WS_CNT0 + WS_CNT_STRIDE * i];
     g_ws_counters[1] += relax_launches;
     g_ws_counters[2] += 1;
     return PCSEG_OK;
