@@ -121,6 +121,36 @@ __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__res
 // (1) minimax relaxation, tile-local fixed point in LDS.  L and the pixel value share one 64-bit LDS word (x = L,
 // y = value): a sweep step is ONE ds_read_b64 instead of two ds_read_b32 -- the kernel is bound by LDS issue, and the
 // b64 form moves twice the bytes per issue slot (odd pitch: conflict-free for row and column sweeps alike).
+// one directional sweep of a line: L(i) = min(L(i), max(value(i), L(previous cell))).  Eight cells are fetched before
+// any of them is updated: the reads of a batch carry no dependency on the batch's writes (a cell is written only when
+// it is processed), and what another wave writes meanwhile is picked up an iteration later, which the monotone update
+// tolerates.  The batch loop is NOT unrolled: four direction-specific bodies have to stay resident in the I-cache.
+#ifndef WS_BATCH
+#define WS_BATCH 8
+#endif
+template <int STEP>
+__device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
+{
+    unsigned *sLw = reinterpret_cast<unsigned *>(sLV);  // the L half of element i is word 2 * i
+    bool changed = false;
+    unsigned prev = sLV[start].x;
+    int base = start + STEP;
+#pragma unroll 1
+    for (int k0 = 0; k0 < WS_T; k0 += WS_BATCH, base += WS_BATCH * STEP) {
+        uint2 lv[WS_BATCH];
+#pragma unroll
+        for (int j = 0; j < WS_BATCH; ++j) lv[j] = sLV[base + j * STEP];
+#pragma unroll
+        for (int j = 0; j < WS_BATCH; ++j) {
+            unsigned cur = lv[j].x;
+            const unsigned cand = max(lv[j].y, prev);
+            if (cand < cur) { sLw[2 * (base + j * STEP)] = cand; cur = cand; changed = true; }
+            prev = cur;
+        }
+    }
+    return changed;
+}
+
 // The FIRST round also does the set-up (what ws_init_kernel does for the exact-only mode): value keys, seed levels and
 // the seed labels are computed while the tile is loaded, so the three input arrays are read once and val / L are not
 // written and read back in between.
@@ -187,21 +217,16 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
     }
     __syncthreads();
     const SweepLine ln = ws_line();
-    unsigned *sLw = reinterpret_cast<unsigned *>(sLV);  // the L half of element i is word 2 * i
+    const int wave = threadIdx.x >> 6;
     bool changed_any = false;
     for (int iter = 0; iter < 100000; ++iter) {
-        bool changed = false;
-        unsigned prev = sLV[ln.start].x;
-        int i = ln.start;
-#pragma unroll 8
-        for (int k = 0; k < WS_T; ++k) {
-            i += ln.step;
-            const uint2 lv = sLV[i];
-            unsigned cur = lv.x;
-            const unsigned cand = max(lv.y, prev);
-            if (cand < cur) { sLw[2 * i] = cand; cur = cand; changed = true; }
-            prev = cur;
-        }
+        // one code path per direction: the step is a compile-time constant there, so the LDS addresses of a batch are
+        // base + constant
+        bool changed;
+        if (wave == 0) changed = ws_sweep<1>(sLV, ln.start);
+        else if (wave == 1) changed = ws_sweep<-1>(sLV, ln.start);
+        else if (wave == 2) changed = ws_sweep<WS_P>(sLV, ln.start);
+        else changed = ws_sweep<-WS_P>(sLV, ln.start);
         if (!__syncthreads_or(changed)) break;
         changed_any = true;
     }
@@ -262,8 +287,13 @@ constexpr int UF_NS = 1 << 30;         // non-seed offset of frame-wide virtual 
 
 __device__ __forceinline__ int vfind_lds(volatile int *par, int v)
 {
+    // path halving: re-pointing v at its grandparent keeps it inside its set (concurrent unions only ever lower parents)
     int p;
-    while ((p = par[v & (UF_LNS - 1)]) != v) v = p;
+    while ((p = par[v & (UF_LNS - 1)]) != v) {
+        const int g = par[p & (UF_LNS - 1)];
+        if (g != p) par[v & (UF_LNS - 1)] = g;
+        v = g;
+    }
     return v;
 }
 __device__ __forceinline__ void vunite_lds(int *par, int a, int b)
