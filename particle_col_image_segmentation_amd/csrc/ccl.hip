@@ -186,29 +186,46 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total)
     return base + inc - v;
 }
 
+// Raster-order numbering = rank of the accepted roots.  Two pixel passes: (1) flatten, count the accepted roots of each
+// SCAN_PIX block and leave -(rank inside the block) at every accepted root; (2) after the block totals were scanned,
+// every pixel decodes its root's entry: negative = block offset - value, positive = a final label that the root's
+// own thread has written meanwhile (both decode to the same number, so the in-place update needs no ordering).
 template <typename Pred>
-__global__ void __launch_bounds__(256) ccl_flatten_count_kernel(int *__restrict__ parent, int *__restrict__ blockcount,
-                                                                 Pred pred, int64_t n, int nblk, bool flatten)
+__global__ void __launch_bounds__(256) ccl_flatten_count_kernel(int *__restrict__ parent, int *__restrict__ labels,
+                                                                 int *__restrict__ blockcount, Pred pred, int64_t n, int nblk,
+                                                                 bool flatten)
 {
     const int b = blockIdx.y;
     int *par = parent + (int64_t)b * n;
     int cnt = 0;
-    int64_t i0 = (int64_t)blockIdx.x * SCAN_PIX + threadIdx.x * 4;
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_PIX + threadIdx.x * 4;
+    int pv[4] = {-1, -1, -1, -1};
+    if ((n & 3) == 0 && i0 + 3 < n) {
+        const int4 v = *reinterpret_cast<const int4 *>(par + i0);
+        pv[0] = v.x; pv[1] = v.y; pv[2] = v.z; pv[3] = v.w;
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < n) pv[j] = par[i0 + j];
+    }
+    bool isroot[4];
     for (int j = 0; j < 4; ++j) {
-        int64_t i = i0 + j;
-        if (i >= n) break;
-        int p = par[i];
-        if (p < 0) continue;
+        const int64_t i = i0 + j;
+        int p = pv[j];
+        isroot[j] = false;
+        if (i >= n || p < 0) continue;
         if (flatten) {
             int x = p, q;
             while ((q = par[x]) != x) x = q;
             if (x != p) par[i] = x;
             p = x;
         }
-        if (p == (int)i && pred((int64_t)b * n + i)) ++cnt;
+        isroot[j] = p == (int)i && pred((int64_t)b * n + i);
+        cnt += isroot[j];
     }
     int total;
-    block_exclusive_scan(cnt, &total);
+    int rank = block_exclusive_scan(cnt, &total);
+    for (int j = 0; j < 4; ++j)
+        if (isroot[j]) labels[(int64_t)b * n + i0 + j] = -(++rank);
     if (threadIdx.x == 0) blockcount[b * nblk + blockIdx.x] = total;
 }
 
@@ -229,40 +246,37 @@ __global__ void __launch_bounds__(256) ccl_scan_blocks_kernel(int *__restrict__ 
 }
 
 template <typename Pred>
-__global__ void __launch_bounds__(256) ccl_assign_kernel(const int *__restrict__ parent, const int *__restrict__ blockoff,
-                                                          int *__restrict__ labels, Pred pred, int64_t n, int nblk)
-{
-    const int b = blockIdx.y;
-    const int *par = parent + (int64_t)b * n;
-    int64_t i0 = (int64_t)blockIdx.x * SCAN_PIX + threadIdx.x * 4;
-    bool isroot[4];
-    int cnt = 0;
-    for (int j = 0; j < 4; ++j) {
-        int64_t i = i0 + j;
-        isroot[j] = i < n && par[i] == (int)i && pred((int64_t)b * n + i);
-        cnt += isroot[j];
-    }
-    int total;
-    int ex = block_exclusive_scan(cnt, &total);
-    int next = blockoff[b * nblk + blockIdx.x] + ex;
-    for (int j = 0; j < 4; ++j)
-        if (isroot[j]) labels[(int64_t)b * n + i0 + j] = ++next;
-}
-
-template <typename Pred>
-__global__ void __launch_bounds__(256) ccl_relabel_kernel(const int *__restrict__ parent, int *__restrict__ labels,
-                                                           Pred pred, int64_t n)
+__global__ void __launch_bounds__(256) ccl_relabel_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
+                                                           Pred pred, int64_t n, int nblk)
 {
     const int b = blockIdx.y;
     const int *par = parent + (int64_t)b * n;
     int *lab = labels + (int64_t)b * n;
-    int64_t i0 = (int64_t)blockIdx.x * SCAN_PIX + threadIdx.x * 4;
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_PIX + threadIdx.x * 4;
+    const bool vec = (n & 3) == 0 && i0 + 3 < n;
+    int pv[4] = {-1, -1, -1, -1};
+    if (vec) {
+        const int4 v = *reinterpret_cast<const int4 *>(par + i0);
+        pv[0] = v.x; pv[1] = v.y; pv[2] = v.z; pv[3] = v.w;
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < n) pv[j] = par[i0 + j];
+    }
+    int out[4];
     for (int j = 0; j < 4; ++j) {
-        int64_t i = i0 + j;
-        if (i >= n) break;
-        int p = par[i];
-        if (p == (int)i && pred((int64_t)b * n + i)) continue;  // accepted roots were written by the assign pass
-        lab[i] = (p >= 0 && pred((int64_t)b * n + p)) ? lab[p] : 0;
+        const int p = pv[j];
+        int v = 0;
+        if (p >= 0 && pred((int64_t)b * n + p)) {
+            v = __hip_atomic_load(lab + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // rank code or final label
+            if (v < 0) v = blockoff[b * nblk + p / SCAN_PIX] - v;
+        }
+        out[j] = v;
+    }
+    if (vec) {
+        *reinterpret_cast<int4 *>(lab + i0) = make_int4(out[0], out[1], out[2], out[3]);
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < n) lab[i0 + j] = out[j];
     }
 }
 
@@ -312,13 +326,11 @@ static int ccl_compact(int *parent, int *blockcount, int nblk, int *labels, int 
 {
     int64_t n = (int64_t)H * W;
     dim3 grid(nblk, B);
-    PCSEG_LAUNCH((ccl_flatten_count_kernel<Pred>), grid, dim3(256), 0, s, parent, blockcount, pred, n, nblk, flatten);
+    PCSEG_LAUNCH((ccl_flatten_count_kernel<Pred>), grid, dim3(256), 0, s, parent, labels, blockcount, pred, n, nblk, flatten);
     PCSEG_CHECK_LAUNCH();
     PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, blockcount, counts, nblk);
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH((ccl_assign_kernel<Pred>), grid, dim3(256), 0, s, parent, blockcount, labels, pred, n, nblk);
-    PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH((ccl_relabel_kernel<Pred>), grid, dim3(256), 0, s, parent, labels, pred, n);
+    PCSEG_LAUNCH((ccl_relabel_kernel<Pred>), grid, dim3(256), 0, s, (const int *)parent, labels, (const int *)blockcount, pred, n, nblk);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }
