@@ -17,10 +17,13 @@ constexpr unsigned G_INF = 0xFFFFu;  // "no zero pixel in this column"
 
 // ---- foreground predicates (distance is measured TO the nearest non-foreground pixel)
 struct FgNzU8 {
+    static constexpr bool kBytes = true;  // one input byte per pixel, no side output: eligible for 4-column loads
     const uint8_t *p;
+    __device__ __forceinline__ bool byte(unsigned v) const { return v != 0; }
     __device__ __forceinline__ bool operator()(int b, int64_t pix, int64_t n) const { return p[b * n + pix] != 0; }
 };
 struct FgLtF32 {
+    static constexpr bool kBytes = false;
     const float *p;
     float thr;
     uint8_t *mask_out;
@@ -33,13 +36,11 @@ struct FgLtF32 {
     }
 };
 struct FgNotInSetU8 {
+    static constexpr bool kBytes = true;
     const uint8_t *p;
     unsigned long long bits;
-    __device__ __forceinline__ bool operator()(int b, int64_t pix, int64_t n) const
-    {
-        unsigned v = p[b * n + pix];
-        return !(v < 64 && ((bits >> v) & 1ull));
-    }
+    __device__ __forceinline__ bool byte(unsigned v) const { return !(v < 64 && ((bits >> v) & 1ull)); }
+    __device__ __forceinline__ bool operator()(int b, int64_t pix, int64_t n) const { return byte(p[b * n + pix]); }
 };
 
 // one thread per (word, column): fg bits of 32 rows
@@ -58,6 +59,30 @@ __global__ void __launch_bounds__(256) edt_bits_kernel(Fg fg, unsigned *__restri
         if (r < H && fg(b, (int64_t)r * W + c, n)) word |= 1u << j;
     }
     bits[((int64_t)b * nch + ch) * W + c] = word;
+}
+
+// byte inputs with W % 4 == 0: a lane takes four adjacent columns (one 4-byte load per row, one 16-byte store)
+template <typename Fg>
+__global__ void __launch_bounds__(256) edt_bits4_kernel(Fg fg, unsigned *__restrict__ bits, int H, int W, int nch)
+{
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    if (c >= W) return;
+    const uint8_t *src = fg.p + (int64_t)b * H * W + c;
+    const int r0 = ch * EDT_CH;
+    unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll 8
+    for (int j = 0; j < EDT_CH; ++j) {
+        const int r = r0 + j;
+        if (r < H) {
+            const unsigned v = *reinterpret_cast<const unsigned *>(src + (int64_t)r * W);
+            if (fg.byte(v & 255u)) w0 |= 1u << j;
+            if (fg.byte((v >> 8) & 255u)) w1 |= 1u << j;
+            if (fg.byte((v >> 16) & 255u)) w2 |= 1u << j;
+            if (fg.byte(v >> 24)) w3 |= 1u << j;
+        }
+    }
+    *reinterpret_cast<uint4 *>(bits + ((int64_t)b * nch + ch) * W + c) = make_uint4(w0, w1, w2, w3);
 }
 
 // per column: distance from the first row of each word to the nearest zero above it (up),
@@ -348,7 +373,14 @@ static int edt_run(Fg fg, Epi epi, unsigned long long *count, int B, int H, int 
     }
     PCSEG_CHECK_HIP(hipMemsetAsync(ws.any_bg, 0, sizeof(int) * B, s));
     dim3 g1((W + 255) / 256, ws.nch, B);
-    PCSEG_LAUNCH((edt_bits_kernel<Fg>), g1, dim3(256), 0, s, fg, ws.bits, H, W, ws.nch);
+    bool wide = false;
+    if constexpr (Fg::kBytes) wide = (W & 3) == 0 && ((uintptr_t)fg.p & 3) == 0 && ((uintptr_t)ws.bits & 15) == 0;
+    if (wide) {
+        if constexpr (Fg::kBytes)
+            PCSEG_LAUNCH((edt_bits4_kernel<Fg>), dim3((W / 4 + 255) / 256, ws.nch, B), dim3(256), 0, s, fg, ws.bits, H, W, ws.nch);
+    } else {
+        PCSEG_LAUNCH((edt_bits_kernel<Fg>), g1, dim3(256), 0, s, fg, ws.bits, H, W, ws.nch);
+    }
     PCSEG_CHECK_LAUNCH();
     PCSEG_LAUNCH(edt_carry_kernel, dim3((W + 255) / 256, B), dim3(256), 0, s, ws.bits, ws.up, ws.dn, ws.any_bg, H, W, ws.nch);
     PCSEG_CHECK_LAUNCH();
