@@ -100,8 +100,8 @@ __device__ __forceinline__ void ws_store_tile(const T *s, T *__restrict__ g, int
 // After a tile converged: wave e compares edge e of the tile (0 top, 1 bottom, 2 left, 3 right) with what is still in
 // global memory and marks only the neighbour that shares a CHANGED edge.  Must run BEFORE the tile is stored.
 template <typename T>
-__device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__restrict__ g, uint8_t *dirty_out, int b, int tx,
-                                                      int ty, int tilesX, int tilesY, int r0, int c0, int H, int W)
+__device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__restrict__ g, uint8_t *dirty_out, int *any_marked,
+                                                      int b, int tx, int ty, int tilesX, int tilesY, int r0, int c0, int H, int W)
 {
     const int e = threadIdx.x >> 6, j = threadIdx.x & 63;
     const int lr = e == 0 ? 1 : (e == 1 ? WS_T : j + 1);
@@ -111,10 +111,13 @@ __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__res
     if (r < H && c < W) ch = s[lr * WS_P + lc] != g[(int64_t)r * W + c];
     if (__any(ch) && j == 0) {
         uint8_t *d = dirty_out + (int64_t)b * tilesX * tilesY;
+        bool marked = true;
         if (e == 0 && ty > 0) d[(ty - 1) * tilesX + tx] = 1;
-        if (e == 1 && ty + 1 < tilesY) d[(ty + 1) * tilesX + tx] = 1;
-        if (e == 2 && tx > 0) d[ty * tilesX + tx - 1] = 1;
-        if (e == 3 && tx + 1 < tilesX) d[ty * tilesX + tx + 1] = 1;
+        else if (e == 1 && ty + 1 < tilesY) d[(ty + 1) * tilesX + tx] = 1;
+        else if (e == 2 && tx > 0) d[ty * tilesX + tx - 1] = 1;
+        else if (e == 3 && tx + 1 < tilesX) d[ty * tilesX + tx + 1] = 1;
+        else marked = false;
+        if (marked && *any_marked == 0) *any_marked = 1;  // the next round has work
     }
 }
 
@@ -550,7 +553,7 @@ __global__ void __launch_bounds__(256) ws_k2_init_kernel(const int *__restrict__
 __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
                                                            unsigned *__restrict__ K2, const uint8_t *__restrict__ active,
                                                            const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
-                                                           int *__restrict__ any_changed, int H, int W, int tilesX, int tilesY)
+                                                           int *__restrict__ any_marked, int H, int W, int tilesX, int tilesY)
 {
     __shared__ unsigned sL[WS_N];
     __shared__ unsigned sK[WS_N];
@@ -588,10 +591,9 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict_
         changed_any = true;
     }
     if (!changed_any) return;
-    ws_mark_changed_edges(sK, (const unsigned *)K2 + fbase, dirty_out, b, tx, ty, tilesX, tilesY, r0, c0, H, W);
+    ws_mark_changed_edges(sK, (const unsigned *)K2 + fbase, dirty_out, any_marked, b, tx, ty, tilesX, tilesY, r0, c0, H, W);
     __syncthreads();
     ws_store_tile(sK, K2 + fbase, r0, c0, H, W);
-    if (threadIdx.x == 0) *any_changed = 1;
 }
 
 // K64 = (L << 32) | K2 inside the active tiles; every other pixel of
@@ -916,25 +918,25 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     }
     const dim3 tgrid(tilesX, tilesY, B);
     const dim3 pgrid((W + 63) / 64, (H + 3) / 4, B);
-    // host-driven fixed point: `launch(din, dout)` enqueues one round; polled every 4 rounds.  `first` = tiles that
-    // start dirty (nullptr: all)
+    // host-driven fixed point: `launch(din, dout, any_marked)` enqueues one round; polled after 4 rounds, then after
+    // every 2; done when the last round of a window marked no tile for the next.  `first` = tiles that start dirty
     auto iterate = [&](const uint8_t *first, auto &&launch) -> int {
-        if (first) PCSEG_CHECK_HIP(hipMemcpyAsync(dirtyA, first, ntiles, hipMemcpyDeviceToDevice, s));
-        else PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 1, ntiles, s));
+        PCSEG_CHECK_HIP(hipMemcpyAsync(dirtyA, first, ntiles, hipMemcpyDeviceToDevice, s));
         uint8_t *din = dirtyA, *dout = dirtyB;
-        for (int round = 0;; round += 4) {
-            PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int), s));
-            for (int k = 0; k < 4; ++k) {
+        for (int round = 0;;) {
+            const int window = round == 0 ? 4 : 2;
+            PCSEG_CHECK_HIP(hipMemsetAsync(changed + 2, 0, sizeof(int), s));
+            for (int k = 0; k < window; ++k, ++round) {
                 PCSEG_CHECK_HIP(hipMemsetAsync(dout, 0, ntiles, s));
-                launch(din, dout);
+                launch(din, dout, changed + (k == window - 1 ? 2 : 3));
                 PCSEG_CHECK_LAUNCH();
                 uint8_t *t = din; din = dout; dout = t;
             }
-            int host_changed = 0;
-            PCSEG_CHECK_HIP(hipMemcpyAsync(&host_changed, changed, sizeof(int), hipMemcpyDeviceToHost, s));
+            int last_marked = 0;
+            PCSEG_CHECK_HIP(hipMemcpyAsync(&last_marked, changed + 2, sizeof(int), hipMemcpyDeviceToHost, s));
             PCSEG_CHECK_HIP(hipStreamSynchronize(s));
-            if (!host_changed) return PCSEG_OK;
-            if (round > 4 * (tilesX * tilesY + 64) * 64) {
+            if (!last_marked) return PCSEG_OK;
+            if (round > (tilesX * tilesY + 64) * 64) {
                 set_error("watershed: fixed point did not converge");
                 return PCSEG_ERR_HIP;
             }
@@ -1058,9 +1060,9 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             PCSEG_LAUNCH(ws_k2_init_kernel, pg2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
                          (const unsigned *)L, markers, mask, (const uint8_t *)active_tiles, K2, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            rc = iterate(active_tiles, [&](uint8_t *din, uint8_t *dout) {
+            rc = iterate(active_tiles, [&](uint8_t *din, uint8_t *dout, int *any_marked) {
                 PCSEG_LAUNCH(ws_k2_relax_kernel, tg2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
-                             (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, changed, H, W, tilesX, tilesY);
+                             (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, any_marked, H, W, tilesX, tilesY);
             });
             if (rc) return rc;
             PCSEG_LAUNCH(ws_pack_kernel, lg2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)L, (const unsigned *)K2,
