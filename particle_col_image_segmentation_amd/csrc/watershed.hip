@@ -628,6 +628,25 @@ __global__ void __launch_bounds__(256) ws_activate_frames_kernel(const int *__re
     out[(int64_t)b * n + i] = mask[(int64_t)b * n + i] ? markers[(int64_t)b * n + i] : 0;
 }
 
+// flagged frames, in order, as a device-side list: the host only needs their number
+__global__ void ws_list_flagged_kernel(const int *__restrict__ flags, int B, int *__restrict__ frame_list, int *__restrict__ count)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int n = 0;
+    for (int b = 0; b < B; ++b)
+        if (flags[b]) frame_list[n++] = b;
+    *count = n;
+}
+
+// the call's tile counters (WS_CNT0 ..) go into a per-device running total, read by pcseg_watershed_counters
+__global__ void ws_accumulate_kernel(const int *__restrict__ changed, unsigned long long *__restrict__ total)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long s = 0;
+    for (int i = 0; i < 16; ++i) s += (unsigned long long)changed[WS_CNT0 + WS_CNT_STRIDE * i];
+    atomicAdd(total, s);
+}
+
 __global__ void ws_set_flags_kernel(int *flags, int B, int v)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -861,16 +880,38 @@ __global__ void __launch_bounds__(256) ws_exact_kernel(const unsigned *__restric
 
 using namespace pcseg;
 
-static long long g_ws_counters[4] = {0, 0, 0, 0};  // relax tiles processed, relax launches, calls, frames to exact path
+static long long g_ws_counters[4] = {0, 0, 0, 0};  // [0] unused (lives on the device), relax launches, calls, -
+static unsigned long long *g_ws_dev_tiles[64] = {nullptr};  // per device: relaxation tiles processed since the last reset
+
+static unsigned long long *ws_dev_tiles()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!g_ws_dev_tiles[dev]) {
+        if (hipMalloc((void **)&g_ws_dev_tiles[dev], sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_ws_dev_tiles[dev], 0, sizeof(unsigned long long));
+    }
+    return g_ws_dev_tiles[dev];
+}
 
 extern "C" {
 
 void pcseg_watershed_counters(int64_t *out, int reset)
 {
-    if (out)
-        for (int i = 0; i < 4; ++i) out[i] = g_ws_counters[i];
-    if (reset)
+    unsigned long long *dev = ws_dev_tiles();
+    if (out) {
+        unsigned long long tiles = 0;
+        if (dev) (void)hipMemcpy(&tiles, dev, sizeof(tiles), hipMemcpyDeviceToHost);  // blocking: waits for the work queued so far
+        out[0] = (int64_t)tiles;
+        for (int i = 1; i < 4; ++i) out[i] = g_ws_counters[i];
+    }
+    if (reset) {
+        if (dev) {
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(dev, 0, sizeof(unsigned long long));
+        }
         for (int i = 0; i < 4; ++i) g_ws_counters[i] = 0;
+    }
 }
 
 size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
@@ -1027,22 +1068,17 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                          (const int *)nullptr, flags, H, W);
             PCSEG_CHECK_LAUNCH();
         }
-        // flags -> host: which frames need the second level (launched over exactly those frames)
-        std::vector<int> flagged;
-        {
-            std::vector<int> host_flags(B);
-            PCSEG_CHECK_HIP(hipMemcpyAsync(host_flags.data(), flags, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-            PCSEG_CHECK_HIP(hipStreamSynchronize(s));
-            for (int b = 0; b < B; ++b)
-                if (host_flags[b]) flagged.push_back(b);
-        }
-        const int nfl = (int)flagged.size();
+        // which frames need the second level (launched over exactly those frames): the list stays on the device, the
+        // host reads how many there are
+        int nfl = 0;
+        PCSEG_LAUNCH(ws_list_flagged_kernel, dim3(1), dim3(64), 0, s, (const int *)flags, B, frame_list, changed + 4);
+        PCSEG_CHECK_LAUNCH();
+        PCSEG_CHECK_HIP(hipMemcpyAsync(&nfl, changed + 4, sizeof(int), hipMemcpyDeviceToHost, s));
+        PCSEG_CHECK_HIP(hipStreamSynchronize(s));
         const int any_flag = nfl > 0;
         if (any_flag) {
             unsigned *K2 = heap_idx;
             unsigned long long *K64 = heap_key;
-            PCSEG_CHECK_HIP(hipMemcpyAsync(frame_list, flagged.data(), sizeof(int) * nfl, hipMemcpyHostToDevice, s));
-            PCSEG_CHECK_HIP(hipStreamSynchronize(s));  // `flagged` is pageable host memory
             const dim3 pg2(pgrid.x, pgrid.y, nfl), lg2(lgrid.x, nfl), tg2(tilesX, tilesY, nfl);
             // the components that hold two marker ids go back to their seeds; their tiles are the second level's work
             PCSEG_LAUNCH(ws_uf_label_kernel<UF_REPAIR>, lg2, dim3(256), 0, s, (const int *)frame_list, (const int *)uf_parent, out,
@@ -1083,10 +1119,10 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         PCSEG_LAUNCH(ws_exact_kernel, dim3(B), dim3(256), 0, s, val, markers, mask, out, flags2, heap_key, heap_idx, H, W);
         PCSEG_CHECK_LAUNCH();
     }
-    int host_counts[WS_CHANGED_INTS];
-    PCSEG_CHECK_HIP(hipMemcpyAsync(host_counts, changed, sizeof(int) * WS_CHANGED_INTS, hipMemcpyDeviceToHost, s));
-    PCSEG_CHECK_HIP(hipStreamSynchronize(s));
-    for (int i = 0; i < 16; ++i) g_ws_counters[0] += host_counts[WS_CNT0 + WS_CNT_STRIDE * i];
+    if (unsigned long long *dev_tiles = ws_dev_tiles()) {
+        PCSEG_LAUNCH(ws_accumulate_kernel, dim3(1), dim3(64), 0, s, (const int *)changed, dev_tiles);
+        PCSEG_CHECK_LAUNCH();
+    }
     g_ws_counters[1] += relax_launches;
     g_ws_counters[2] += 1;
     return PCSEG_OK;

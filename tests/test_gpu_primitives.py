@@ -221,6 +221,22 @@ def test_watershed_golden(ops, primitives, mode):
         assert n_flagged > 0  # quantised cases must have gone through the exact path
 
 
+@pytest.mark.parametrize("shape", [(64, 64), (65, 129), (130, 257), (193, 64), (300, 500), (31, 700)])
+def test_watershed_odd_shapes(ops, shape):
+    """Frame sizes around the tile edges: the relaxation alternates between the 64-aligned tiling and the one shifted by
+    half a tile (one more tile per axis, partial tiles on every side); labels must match the oracle bit for bit."""
+    from particle_col_image_segmentation_amd import synth
+    H, W = shape
+    st = synth.gen_batch(300 + H + W, 2, H, W)
+    bm = np.ascontiguousarray(st[:, 3])
+    refs = [orc.refine_boundaries(b) for b in bm]
+    mk = np.stack([r["markers"] for r in refs])
+    ms = np.stack([r["binary_mask"] for r in refs])
+    out, _ = ops.watershed(dev(bm), dev(mk), dev(ms), mode=0)
+    for i in range(2):
+        np.testing.assert_array_equal(host(out)[i], refs[i]["labels"])
+
+
 def test_watershed_exact_path_deep_heap(ops):
     """Mode 1 = the heap emulation alone, on quantised frames large enough for the heap to outgrow its LDS levels
     (4095 slots) so that the workspace levels, the 5-level descents and long sift-ups are all exercised."""
