@@ -135,7 +135,7 @@ template <int STEP>
 __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
 {
     unsigned *sLw = reinterpret_cast<unsigned *>(sLV);  // the L half of element i is word 2 * i
-    bool changed = false;
+    unsigned diff = 0;  // != 0 once a cell of this line was lowered
     unsigned prev = sLV[start].x;
     int base = start + STEP;
 #pragma unroll 1
@@ -147,11 +147,17 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
         for (int j = 0; j < WS_BATCH; ++j) {
             unsigned cur = lv[j].x;
             const unsigned cand = max(lv[j].y, prev);
-            if (cand < cur) { sLw[2 * (base + j * STEP)] = cand; cur = cand; changed = true; }
+            // unconditional LDS atomic min: nothing under an exec mask on the dependency chain (a compare + masked
+            // store + masked move per step cost 10 % more), and still monotone when another wave lowered the cell
+            // since the batch was read
+            atomicMin(&sLw[2 * (base + j * STEP)], cand);
+            const unsigned nw = min(cur, cand);
+            diff |= cur ^ nw;
+            cur = nw;
             prev = cur;
         }
     }
-    return changed;
+    return diff != 0;
 }
 
 // The FIRST round also does the set-up (what ws_init_kernel does for the exact-only mode): value keys, seed levels and
