@@ -30,8 +30,9 @@ CHAIN_BYTES_PER_PIXEL = 28  # 5 x f32 in + int32 class-CC mask +
 # algorithmic (compulsory) bytes per pixel of one launch of each kernel, stated in DESIGN.md
 KERNEL_BYTES_PER_PIXEL = {
     "argmax_kernel": 21.0, "median5_kernel": 2.0, "ccl_tile_kernel": 5.0, "ccl_border_kernel": 0.0,
-    "ccl_flatten_count_kernel": 8.0, "ccl_assign_kernel": 4.0, "ccl_relabel_kernel": 8.0, "ccl_flatten_kernel": 8.0,
-    "region_reduce_kernel": 24.0, "region_reduce_col_kernel": 24.0, "edt_bits_kernel": 1.0, "edt_row_kernel": 4.0,
+    "ccl_flatten_count_kernel": 8.0, "ccl_relabel_kernel": 8.0, "ccl_flatten_kernel": 8.0,
+    "region_reduce_kernel": 24.0, "region_reduce_col_kernel": 24.0, "edt_bits_kernel": 1.0, "edt_bits4_kernel": 1.0,
+    "edt_row_kernel": 4.0, "edt_reach_kernel": 2.0,
     "ws_init_kernel": 21.0, "ws_relax_kernel": 12.0, "ws_k2_relax_kernel": 12.0, "ws_uf_tile_kernel": 13.0,
     "ws_uf_border_kernel": 0.0, "ws_uf_label_kernel": 12.0, "ws_check_kernel": 8.0,
     "ws_exact_kernel": 21.0, "locmax_candidates_kernel": 8.0, "locmax_bad_kernel": 8.0,
