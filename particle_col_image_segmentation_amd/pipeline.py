@@ -27,7 +27,39 @@ RATIOS_5 = (("C13act", 1, (1, 0)), ("N15act", 3, (2, 3)))
 
 
 class BatchResult(dict):
-    """Device tensors of one batch (see FramePipeline.run for the keys)."""
+    """Device tensors of one batch (see FramePipeline.run for the keys).
+
+    ``FramePipeline.run`` returns as soon as both kernel chains are enqueued; reading any entry waits (once) for the two
+    events that close them, so callers never see unfinished tensors, while a loop that only calls ``run`` keeps the
+    next batch's class-map chain running under this batch's watershed tail."""
+
+    _pending = None
+
+    def synchronize(self):
+        pending, self._pending = self._pending, None
+        for ev in pending or ():
+            ev.synchronize()
+        return self
+
+    def __getitem__(self, key):
+        if self._pending:
+            self.synchronize()
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        if self._pending:
+            self.synchronize()
+        return dict.get(self, key, default)
+
+    def items(self):
+        if self._pending:
+            self.synchronize()
+        return dict.items(self)
+
+    def values(self):
+        if self._pending:
+            self.synchronize()
+        return dict.values(self)
 
     def check(self):
         """Raise for the conditions the reference raises for / the tables cannot hold."""
@@ -76,8 +108,13 @@ class FramePipeline:
             self._class_chain(stack, res)
         with torch.cuda.stream(s2):
             self._refine_chain(stack, res)
-        s1.synchronize()
-        s2.synchronize()
+        # no host wait here: the result carries the two closing events (BatchResult.synchronize)
+        done = (torch.cuda.Event(), torch.cuda.Event())
+        done[0].record(s1)
+        done[1].record(s2)
+        stack.record_stream(s1)
+        stack.record_stream(s2)
+        res._pending = done
         return res
 
     def _class_chain(self, stack, res):
