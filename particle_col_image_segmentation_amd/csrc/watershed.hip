@@ -186,13 +186,20 @@ struct WsTiling {
 };
 
 __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool FIRST, unsigned *__restrict__ val,
-                                                        unsigned *__restrict__ L, const uint8_t *__restrict__ dirty_in,
+                                                        unsigned *__restrict__ L, uint8_t *__restrict__ dirty_in,
                                                         uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed,
                                                         int *__restrict__ any_marked, int H, int W, WsTiling cur, WsTiling nxt)
 {
     __shared__ uint2 sLV[WS_N];
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
-    if (!FIRST && !dirty_in[((int64_t)b * cur.ny + ty) * cur.nx + tx]) return;
+    if (!FIRST) {
+        // a visited tile takes its mark down itself: the buffer is all zero again when it becomes the output of the
+        // round after next, and no memset has to sit between two rounds
+        uint8_t *mark = dirty_in + ((int64_t)b * cur.ny + ty) * cur.nx + tx;
+        if (!*mark) return;
+        __syncthreads();
+        if (threadIdx.x == 0) *mark = 0;
+    }
     // tiles actually processed (measurement: bench.py roofline), spread over 16 cache lines: one counter would make
     // every block of the launch queue on the same line
     if (threadIdx.x == 0) atomicAdd(any_changed + WS_CNT0 + WS_CNT_STRIDE * ((tx + 5 * ty + 3 * b) & 15), 1);
@@ -558,7 +565,7 @@ __global__ void __launch_bounds__(256) ws_k2_init_kernel(const int *__restrict__
 
 __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
                                                            unsigned *__restrict__ K2, const uint8_t *__restrict__ active,
-                                                           const uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
+                                                           uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
                                                            int *__restrict__ any_marked, int H, int W, int tilesX, int tilesY)
 {
     __shared__ unsigned sL[WS_N];
@@ -566,7 +573,12 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict_
     __shared__ uint8_t sLake[WS_N];
     const int tx = blockIdx.x, ty = blockIdx.y, b = ws_frame(frame_list, blockIdx.z);
     if (!active[((int64_t)b * tilesY + ty) * tilesX + tx]) return;  // K2 is only defined inside the active tiles
-    if (!dirty_in[((int64_t)b * tilesY + ty) * tilesX + tx]) return;
+    {
+        uint8_t *mark = dirty_in + ((int64_t)b * tilesY + ty) * tilesX + tx;
+        if (!*mark) return;
+        __syncthreads();
+        if (threadIdx.x == 0) *mark = 0;  // see ws_relax_kernel
+    }
     const int r0 = ty * WS_T, c0 = tx * WS_T;
     const int64_t fbase = (int64_t)b * H * W;
     ws_load_tile(sL, L + fbase, r0, c0, H, W, WS_INF);
@@ -886,6 +898,22 @@ __global__ void __launch_bounds__(256) ws_exact_kernel(const unsigned *__restric
 
 using namespace pcseg;
 
+// two pinned host ints + two events per host thread: verdicts of the fixed-point windows (see fixed_point below)
+struct PollSlots {
+    int *host = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+static PollSlots *poll_slots()
+{
+    static thread_local PollSlots slots;
+    if (!slots.host) {
+        if (hipHostMalloc((void **)&slots.host, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+        for (int i = 0; i < 2; ++i)
+            if (hipEventCreateWithFlags(&slots.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &slots;
+}
+
 static long long g_ws_counters[4] = {0, 0, 0, 0};  // [0] unused (lives on the device), relax launches, calls, -
 static unsigned long long *g_ws_dev_tiles[64] = {nullptr};  // per device: relaxation tiles processed since the last reset
 
@@ -965,30 +993,46 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     }
     const dim3 tgrid(tilesX, tilesY, B);
     const dim3 pgrid((W + 63) / 64, (H + 3) / 4, B);
-    // host-driven fixed point: `launch(din, dout, any_marked)` enqueues one round; polled after 4 rounds, then after
-    // every 2; done when the last round of a window marked no tile for the next.  `first` = tiles that start dirty
-    auto iterate = [&](const uint8_t *first, auto &&launch) -> int {
-        PCSEG_CHECK_HIP(hipMemcpyAsync(dirtyA, first, ntiles, hipMemcpyDeviceToDevice, s));
+    // Host-driven fixed point.  `launch_round(round, din, dout, any_marked)` enqueues one round that visits the tiles
+    // marked in `din` (each takes its own mark down), marks the next round's tiles in `dout` and raises *any_marked if
+    // it marked any.  The first window has `first_window` rounds, later ones two; a window's verdict (did its last
+    // round mark anything?) travels to pinned host memory behind an event, and the NEXT window is already enqueued
+    // when the host looks at it: if the verdict is "nothing marked", that speculative window finds no marks and its
+    // blocks leave at once, otherwise the GPU never waited for the host.
+    PollSlots *poll = poll_slots();
+    if (!poll) {
+        set_error("watershed: cannot allocate pinned poll slots");
+        return PCSEG_ERR_HIP;
+    }
+    auto fixed_point = [&](int first_window, int max_rounds, auto &&launch_round) -> int {
         uint8_t *din = dirtyA, *dout = dirtyB;
-        for (int round = 0;;) {
-            const int window = round == 0 ? 4 : 2;
-            PCSEG_CHECK_HIP(hipMemsetAsync(changed + 2, 0, sizeof(int), s));
-            for (int k = 0; k < window; ++k, ++round) {
-                PCSEG_CHECK_HIP(hipMemsetAsync(dout, 0, ntiles, s));
-                launch(din, dout, changed + (k == window - 1 ? 2 : 3));
+        int round = 0;
+        auto window = [&](int rounds, int slot) -> int {
+            int *flag = changed + (slot ? 5 : 2);
+            PCSEG_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+            for (int k = 0; k < rounds; ++k, ++round) {
+                launch_round(round, din, dout, k == rounds - 1 ? flag : changed + 3);
                 PCSEG_CHECK_LAUNCH();
                 uint8_t *t = din; din = dout; dout = t;
             }
-            int last_marked = 0;
-            PCSEG_CHECK_HIP(hipMemcpyAsync(&last_marked, changed + 2, sizeof(int), hipMemcpyDeviceToHost, s));
-            PCSEG_CHECK_HIP(hipStreamSynchronize(s));
-            if (!last_marked) return PCSEG_OK;
-            if (round > (tilesX * tilesY + 64) * 64) {
+            PCSEG_CHECK_HIP(hipMemcpyAsync(poll->host + slot, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+            PCSEG_CHECK_HIP(hipEventRecord(poll->ev[slot], s));
+            return PCSEG_OK;
+        };
+        int rc = window(first_window, 0);
+        if (rc) return rc;
+        for (int cur = 0;; cur ^= 1) {
+            rc = window(2, cur ^ 1);  // speculative
+            if (rc) return rc;
+            PCSEG_CHECK_HIP(hipEventSynchronize(poll->ev[cur]));
+            if (!poll->host[cur]) return PCSEG_OK;
+            if (round > max_rounds) {
                 set_error("watershed: fixed point did not converge");
                 return PCSEG_ERR_HIP;
             }
         }
     };
+    const int max_rounds = (tilesX * tilesY + 64) * 64;
     PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int) * WS_CHANGED_INTS, s));
     long long relax_launches = 0;
     if (mode == 1) {
@@ -1001,33 +1045,15 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         const WsInputs inputs{img, frame_stride, markers, mask, out};
         // minimax relaxation: host-driven rounds over alternating tilings, polled every 4 rounds
         const WsTiling tilings[2] = {{0, tilesX, tilesY}, {WS_T / 2, (W + WS_T / 2 + WS_T - 1) / WS_T, (H + WS_T / 2 + WS_T - 1) / WS_T}};
-        int rc = PCSEG_OK;
-        {
-            // polled after 8 rounds, then after every 2: the fixed point is reached when a round marks no tile for the
-            // next one (changed[2] belongs to the last round of a window, changed[3] collects the others')
-            uint8_t *din = dirtyA, *dout = dirtyB;
-            for (int round = 0;;) {
-                const int window = round == 0 ? 8 : 2;
-                PCSEG_CHECK_HIP(hipMemsetAsync(changed + 2, 0, sizeof(int), s));
-                for (int k = 0; k < window; ++k, ++round) {
-                    const WsTiling &cur = tilings[round & 1], &nxt = tilings[(round + 1) & 1];
-                    PCSEG_CHECK_HIP(hipMemsetAsync(dout, 0, ntiles_max, s));
-                    PCSEG_LAUNCH(ws_relax_kernel, dim3(cur.nx, cur.ny, B), dim3(256), 0, s, inputs, round == 0, val, L,
-                                 (const uint8_t *)din, dout, changed, changed + (k == window - 1 ? 2 : 3), H, W, cur, nxt);
-                    PCSEG_CHECK_LAUNCH();
-                    ++relax_launches;
-                    uint8_t *t = din; din = dout; dout = t;
-                }
-                int last_marked = 0;
-                PCSEG_CHECK_HIP(hipMemcpyAsync(&last_marked, changed + 2, sizeof(int), hipMemcpyDeviceToHost, s));
-                PCSEG_CHECK_HIP(hipStreamSynchronize(s));
-                if (!last_marked) break;
-                if (round > (tilesX * tilesY + 64) * 64) {
-                    set_error("watershed: fixed point did not converge");
-                    return PCSEG_ERR_HIP;
-                }
-            }
-        }
+        // both mark buffers start empty (round 0 visits every tile regardless)
+        PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, ntiles_max, s));
+        PCSEG_CHECK_HIP(hipMemsetAsync(dirtyB, 0, ntiles_max, s));
+        int rc = fixed_point(8, max_rounds, [&](int round, uint8_t *din, uint8_t *dout, int *any_marked) {
+            const WsTiling &cur = tilings[round & 1], &nxt = tilings[(round + 1) & 1];
+            PCSEG_LAUNCH(ws_relax_kernel, dim3(cur.nx, cur.ny, B), dim3(256), 0, s, inputs, round == 0, val, L, din, dout, changed,
+                         any_marked, H, W, cur, nxt);
+            ++relax_launches;
+        });
         if (rc) return rc;
         const dim3 ugrid((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B);
         const dim3 lgrid((unsigned)(((size_t)H * W + 255) / 256), B);
@@ -1102,7 +1128,10 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             PCSEG_LAUNCH(ws_k2_init_kernel, pg2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
                          (const unsigned *)L, markers, mask, (const uint8_t *)active_tiles, K2, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            rc = iterate(active_tiles, [&](uint8_t *din, uint8_t *dout, int *any_marked) {
+            // marks of the first round = the active tiles; the other buffer (it held the active set) starts empty
+            PCSEG_CHECK_HIP(hipMemcpyAsync(dirtyA, active_tiles, ntiles, hipMemcpyDeviceToDevice, s));
+            PCSEG_CHECK_HIP(hipMemsetAsync(dirtyB, 0, ntiles_max, s));
+            rc = fixed_point(4, max_rounds, [&](int, uint8_t *din, uint8_t *dout, int *any_marked) {
                 PCSEG_LAUNCH(ws_k2_relax_kernel, tg2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
                              (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, any_marked, H, W, tilesX, tilesY);
             });
