@@ -366,7 +366,11 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__
         sK[i] = (r >= 0 && r < H && c >= 0 && c < W) ? K[fbase + (int64_t)r * W + c] : KINF;
     }
     __syncthreads();
-    int self[UF_LNS / 256];  // own virtual index of the pixels this thread handles (-1: unreachable / outside)
+    // (1) per pixel: own virtual index and which neighbours hold the minimum neighbour key (bit0 up, 1 left, 2 right,
+    // 3 down; 0 for seeds / unreachable).  The masks also go to global memory for the border pass, which then needs
+    // two bytes per cross-tile pair instead of ten keys.
+    __shared__ uint8_t sM[UF_LNS];
+    int self[UF_LNS / 256];  // -1: unreachable / outside
 #pragma unroll
     for (int k = 0; k < UF_LNS / 256; ++k) {
         const int t = threadIdx.x + k * 256;
@@ -376,31 +380,56 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__
         int v = -1;
         if ((unsigned)(sK[i] >> (8 * sizeof(KeyT) - 32)) != WS_INF)  // reachable => inside the frame
             v = F[fbase + (int64_t)r * W + c] != 0 ? t : t + UF_LNS;  // labelled pixels (seeds) order first
-        self[k] = v;
-        par[t] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < UF_LNS / 256; ++k) {
-        const int t = threadIdx.x + k * 256;
-        const int lr = t / UF_TW, lc = t % UF_TW;
-        const int r = r0 + lr, c = c0 + lc;
-        if (r >= H || c >= W) continue;
-        // which neighbours hold the minimum neighbour key (bit0 up, 1 left, 2 right, 3 down); 0 for seeds / unreachable.
-        // Written for the border pass, which then needs two bytes per cross-tile pair instead of ten keys.
         uint8_t m8 = 0;
-        if (self[k] >= UF_LNS) {  // seeds take no label from neighbours
-            const int i = (lr + 1) * UF_SW + lc + 1;
+        if (v >= UF_LNS) {  // seeds take no label from neighbours
             const KeyT ku = sK[i - UF_SW], kl = sK[i - 1], kr = sK[i + 1], kd = sK[i + UF_SW];
             const KeyT m = min(min(ku, kd), min(kl, kr));
             if (m != KINF) m8 = (ku == m ? 1 : 0) | (kl == m ? 2 : 0) | (kr == m ? 4 : 0) | (kd == m ? 8 : 0);
         }
-        minmask[fbase + (int64_t)r * W + c] = m8;
-        // a neighbour's current parent is a node of the neighbour's set: a valid starting point for the union
-        if ((m8 & 1) && lr > 0) vunite_lds(par, self[k], par[t - UF_TW]);
-        if ((m8 & 2) && lc > 0) vunite_lds(par, self[k], par[t - 1]);
-        if ((m8 & 4) && lc < UF_TW - 1) vunite_lds(par, self[k], par[t + 1]);
-        if ((m8 & 8) && lr < UF_TH - 1) vunite_lds(par, self[k], par[t + UF_TW]);
+        self[k] = v;
+        sM[t] = m8;
+        if (r < H && c < W) minmask[fbase + (int64_t)r * W + c] = m8;
+    }
+    __syncthreads();
+    // (2) row runs without atomics: a wave covers one 64-pixel tile row per trip; pixels joined by horizontal links form
+    // a run, every pixel of it points straight at the run's smallest virtual index (its first seed if it has one,
+    // else its first pixel)
+#pragma unroll
+    for (int k = 0; k < UF_LNS / 256; ++k) {
+        const int t = threadIdx.x + k * 256;
+        const int lc = t % UF_TW;
+        const bool joins_left = lc > 0 && ((sM[t] & 2) || (sM[t - 1] & 4));
+        const unsigned long long heads = __ballot(!joins_left);
+        const unsigned long long seeds = __ballot(self[k] >= 0 && self[k] < UF_LNS);
+        const unsigned long long upto = heads & (lc == 63 ? ~0ull : ((2ull << lc) - 1ull));
+        const int start = 63 - __clzll((long long)upto);
+        const unsigned long long later = lc == 63 ? 0ull : (heads >> (lc + 1));
+        const int end = later ? lc + (__ffsll((long long)later) - 1) : 63;  // last pixel of the run
+        const unsigned long long run = (end == 63 ? ~0ull : ((2ull << end) - 1ull)) & ~((1ull << start) - 1ull);
+        const unsigned long long run_seeds = seeds & run;
+        int root = -1;
+        if (self[k] >= 0) {
+            if (run_seeds) root = (t - lc) + (__ffsll((long long)run_seeds) - 1);  // a seed: virtual index = position
+            else root = (t - lc) + start + UF_LNS;
+        }
+        par[t] = root;
+    }
+    __syncthreads();
+    // (3) vertical links, skipped where three links that are made anyway already imply them (the left neighbour is in
+    // the same run, so is the upper-left one with the upper one, and the left neighbour has its own vertical link)
+#pragma unroll
+    for (int k = 0; k < UF_LNS / 256; ++k) {
+        const int t = threadIdx.x + k * 256;
+        const int lr = t / UF_TW, lc = t % UF_TW;
+        if (lr == 0 || self[k] < 0) continue;
+        const uint8_t m = sM[t], mu = sM[t - UF_TW];
+        if (!((m & 1) || (mu & 8))) continue;
+        if (lc > 0) {
+            const uint8_t ml = sM[t - 1], mul = sM[t - UF_TW - 1];
+            const bool same_run = (m & 2) || (ml & 4), same_run_up = (mu & 2) || (mul & 4), left_vertical = (ml & 1) || (mul & 8);
+            if (same_run && same_run_up && left_vertical) continue;
+        }
+        vunite_lds(par, par[t], par[t - UF_TW]);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < UF_TH * UF_TW; t += 256) {
