@@ -472,11 +472,33 @@ __global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict
     const int64_t fbase = (int64_t)b * H * W;
     int *par = parent + fbase;
     const int p = r * W + c;
-    const uint8_t mp = minmask[fbase + p];
-    if (top && ws_active(active, b, r - 1, c, tilesX, tilesY) && ((mp & 1) || (minmask[fbase + p - W] & 8)))
-        vunite_glb(par, p, p - W);
-    if (left && ws_active(active, b, r, c - 1, tilesX, tilesY) && ((mp & 2) || (minmask[fbase + p - 1] & 4)))
-        vunite_glb(par, p, p - 1);
+    const uint8_t *mm = minmask + fbase;
+    const uint8_t mp = mm[p];
+    // A cross-tile link is skipped when three links that are made anyway already join the two pixels: for a vertical
+    // one the horizontal links p ~ p-1 and p-W ~ p-W-1 (both inside one tile) and the vertical link of p-1; likewise
+    // for a horizontal one.  (At a tile corner both links cross tiles and would justify each other: keep both there.)
+    if (top && ws_active(active, b, r - 1, c, tilesX, tilesY)) {
+        const uint8_t mu = mm[p - W];
+        if ((mp & 1) || (mu & 8)) {
+            bool implied = false;
+            if (!left && c > 0) {
+                const uint8_t ml = mm[p - 1], mul = mm[p - W - 1];
+                implied = ((mp & 2) || (ml & 4)) && ((mu & 2) || (mul & 4)) && ((ml & 1) || (mul & 8));
+            }
+            if (!implied) vunite_glb(par, p, p - W);
+        }
+    }
+    if (left && ws_active(active, b, r, c - 1, tilesX, tilesY)) {
+        const uint8_t ml = mm[p - 1];
+        if ((mp & 2) || (ml & 4)) {
+            bool implied = false;
+            if (!top && r > 0) {
+                const uint8_t mu = mm[p - W], mul = mm[p - W - 1];
+                implied = ((mp & 1) || (mu & 8)) && ((ml & 1) || (mul & 8)) && ((mu & 2) || (mul & 4));
+            }
+            if (!implied) vunite_glb(par, p, p - 1);
+        }
+    }
 }
 
 // Labels from the roots.  A component that holds two differently labelled pixels cannot be resolved at this level:
