@@ -550,6 +550,45 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
     }
 }
 
+// UF_OPTIMISTIC over whole frames with W % 4 == 0: four pixels per lane (16-byte parent / label accesses; neighbours
+// mostly share their root, so the walk is repeated only when the parent entry changes)
+__global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict__ parent, int *__restrict__ F, uint8_t *__restrict__ bad,
+                                                            int *__restrict__ tie_flags, int64_t n)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int b = blockIdx.y;
+    if (i >= n) return;
+    const int64_t fbase = (int64_t)b * n;
+    const int *par = parent + fbase;
+    const int4 p4 = *reinterpret_cast<const int4 *>(par + i);
+    int4 f4 = *reinterpret_cast<const int4 *>(F + fbase + i);
+    const int pv[4] = {p4.x, p4.y, p4.z, p4.w};
+    int fv[4] = {f4.x, f4.y, f4.z, f4.w};
+    int last_p = -1, last_root = -1, last_lab = 0;
+    bool wrote = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int x = pv[j];
+        if (x < 0) continue;
+        if (x != last_p) {
+            last_p = x;
+            int q;
+            while ((q = par[x & (UF_NS - 1)]) != x) x = q;
+            last_root = x;
+            last_lab = x < UF_NS ? F[fbase + x] : 0;  // roots are labelled pixels, never changed by this pass
+        }
+        if (last_root >= UF_NS) continue;  // no labelled pixel in the component
+        if (fv[j] == 0) {
+            fv[j] = last_lab;
+            wrote = true;
+        } else if (fv[j] != last_lab) {
+            bad[fbase + last_root] = 1;
+            if (tie_flags[b] == 0) tie_flags[b] = 1;
+        }
+    }
+    if (wrote) *reinterpret_cast<int4 *>(F + fbase + i) = make_int4(fv[0], fv[1], fv[2], fv[3]);
+}
+
 // (3) proof check: every neighbour whose key equals the minimum neighbour key carries the pixel's label
 template <typename KeyT>
 __global__ void __launch_bounds__(256) ws_check_kernel(const KeyT *__restrict__ K, const int *__restrict__ F,
@@ -1125,7 +1164,11 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                              tilesX, tilesY);
                 PCSEG_CHECK_LAUNCH();
             }
-            if (first_level) {
+            if (first_level && act == nullptr && flist == nullptr && (W & 3) == 0 && ((uintptr_t)out & 15) == 0) {
+                PCSEG_LAUNCH(ws_uf_label4_kernel, dim3((unsigned)((npx / 4 + 255) / 256), nframes), dim3(256), 0, s,
+                             (const int *)uf_parent, out, uf_bad1, out_flags, npx);
+                PCSEG_CHECK_LAUNCH();
+            } else if (first_level) {
                 PCSEG_LAUNCH(ws_uf_label_kernel<UF_OPTIMISTIC>, lg, dim3(256), 0, s, flist, (const int *)uf_parent, out, act,
                              uf_bad1, markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY);
                 PCSEG_CHECK_LAUNCH();
