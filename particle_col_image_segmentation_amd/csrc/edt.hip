@@ -7,6 +7,8 @@
 // as uint16, and the horizontal pass is an expanding search that stops as soon
 // as k*k >= best (exact: the candidate at offset k is >= k*k).  HBM traffic is
 // the input read plus the int32 (or uint8) result write.
+#include <type_traits>
+
 #include "common.h"
 
 namespace pcseg {
@@ -172,26 +174,38 @@ struct EpiFillParticle {
     }
 };
 
-template <typename Epi>
+// Horizontal pass for the distance itself.  The block stages the SQUARED vertical distances of its rows in LDS as
+// uint32 (EDT_D2_INF where the column has no zero pixel; one such guard cell either side of a row, so the search needs
+// no bounds tests, only clamped indices); a candidate then costs an add and a min.  The search expands four offsets per
+// trip (the 8 LDS reads are issued together) and stops as soon as k^2 >= best, which is exact: offsets past the exit
+// point are still true candidates (g^2 + k^2 of a real pixel), and no closer one is left.
+constexpr unsigned EDT_D2_INF = 0x40000000u;  // > any g^2 (g <= 32767); g^2 + k^2 stays below 2^32
+
+template <typename Epi, int RB>
 __global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict__ bits, const uint16_t *__restrict__ up,
                                                        const uint16_t *__restrict__ dn, const int *__restrict__ any_bg,
                                                        Epi epi, unsigned long long *__restrict__ count, int H, int W, int nch)
 {
-    extern __shared__ __attribute__((aligned(16))) uint16_t g[];  // [EDT_RB][W]
+    extern __shared__ __attribute__((aligned(16))) unsigned g2[];  // [RB][W + 2]
+    const int P = W + 2;
     const int b = blockIdx.y;
-    const int r0 = blockIdx.x * EDT_RB;
+    const int r0 = blockIdx.x * RB;
     const int ch = r0 / EDT_CH, j0 = r0 % EDT_CH;
     const int rows_in_word = min(EDT_CH, H - ch * EDT_CH);
     const unsigned valid = rows_in_word == 32 ? 0xFFFFFFFFu : ((1u << rows_in_word) - 1u);
-    const int nrows = min(EDT_RB, H - r0);
+    const int nrows = min(RB, H - r0);
     const int64_t wbase = ((int64_t)b * nch + ch) * W;
     for (int c = threadIdx.x; c < W; c += 256) {
         unsigned word = bits[wbase + c];
         unsigned u = up[wbase + c], d = dn[wbase + c];
 #pragma unroll
-        for (int j = 0; j < EDT_RB; ++j)
-            if (j < nrows) g[j * W + c] = (uint16_t)vdist(word, valid, j0 + j, u, d, rows_in_word);
+        for (int j = 0; j < RB; ++j)
+            if (j < nrows) {
+                const unsigned v = vdist(word, valid, j0 + j, u, d, rows_in_word);
+                g2[j * P + c + 1] = v == G_INF ? EDT_D2_INF : v * v;
+            }
     }
+    if (threadIdx.x < 2 * RB) g2[(threadIdx.x >> 1) * P + ((threadIdx.x & 1) ? W + 1 : 0)] = EDT_D2_INF;
     __syncthreads();
     const bool anybg = any_bg[b] != 0;
     const int kmax = epi.kmax(W);
@@ -200,31 +214,23 @@ __global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict
     for (int idx = threadIdx.x; idx < nrows * W; idx += 256) {
         const int j = idx / W, c = idx % W;
         const int64_t gi = fbase + (int64_t)(r0 + j) * W + c;
-        const uint16_t *gr = g + j * W;
-        // 32-bit arithmetic is exact here: g <= 32767 and k < 32768, so g*g + k*k < 2^31
-        unsigned best;
-        {
-            unsigned g0 = gr[c];
-            best = g0 == G_INF ? 0xFFFFFFFFu : g0 * g0;
-            // four offsets per trip: the 8 LDS reads are issued together; offsets past the exit point are still true
-            // candidates (g^2 + k^2 of a real pixel), so the minimum stays exact
-            for (int k = 1; k <= kmax && (unsigned)(k * k) < best; k += 4) {
-                if (c - k < 0 && c + k >= W) break;
-                unsigned gl[4], gq[4];
+        const unsigned *gr = g2 + j * P + 1;  // gr[-1] and gr[W] are the guard cells
+        unsigned best = gr[c];
+        for (int k = 1; k <= kmax && (unsigned)(k * k) < best; k += 4) {
+            if (c - k < 0 && c + k >= W) break;
+            unsigned gl[4], gq[4];
 #pragma unroll
-                for (int j2 = 0; j2 < 4; ++j2) {
-                    gl[j2] = c - k - j2 >= 0 ? gr[c - k - j2] : G_INF;
-                    gq[j2] = c + k + j2 < W ? gr[c + k + j2] : G_INF;
-                }
+            for (int j2 = 0; j2 < 4; ++j2) {
+                gl[j2] = gr[max(c - k - j2, -1)];
+                gq[j2] = gr[min(c + k + j2, W)];
+            }
 #pragma unroll
-                for (int j2 = 0; j2 < 4; ++j2) {
-                    const unsigned kk = (unsigned)((k + j2) * (k + j2));
-                    if (gl[j2] != G_INF) best = min(best, gl[j2] * gl[j2] + kk);
-                    if (gq[j2] != G_INF) best = min(best, gq[j2] * gq[j2] + kk);
-                }
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const unsigned kk = (unsigned)((k + j2) * (k + j2));
+                best = min(best, min(gl[j2], gq[j2]) + kk);
             }
         }
-        epi.store(gi, best == 0xFFFFFFFFu ? (1ll << 40) : (long long)best, anybg, r0 + j, c, cnt);
+        epi.store(gi, best >= EDT_D2_INF ? (1ll << 40) : (long long)best, anybg, r0 + j, c, cnt);
     }
     if (count) {
         for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
@@ -367,7 +373,7 @@ static int edt_run(Fg fg, Epi epi, unsigned long long *count, int B, int H, int 
         return PCSEG_ERR_WORKSPACE;
     }
     size_t lds = (size_t)EDT_RB * W * sizeof(uint16_t);
-    if (lds > 160 * 1024) {
+    if (Epi::kThreshold && lds > 160 * 1024) {
         set_error("%s: W = %d too wide for the LDS row stage", who, W);
         return PCSEG_ERR_ARG;
     }
@@ -395,9 +401,22 @@ static int edt_run(Fg fg, Epi epi, unsigned long long *count, int B, int H, int 
             PCSEG_LAUNCH(edt_count_kernel, dim3(B), dim3(64), 0, s, (const unsigned long long *)ws.block_counts, (int)g2.x, count);
         }
     } else {
-        if (lds > 64 * 1024)
-            PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)edt_row_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PCSEG_LAUNCH((edt_row_kernel<Epi>), g2, dim3(256), lds, s, ws.bits, ws.up, ws.dn, ws.any_bg, epi, count, H, W, ws.nch);
+        // rows per block: as many as fit the LDS (uint32 per column and row, two guard cells per row)
+        auto launch_rows = [&](auto rb_tag) -> int {
+            constexpr int RB = decltype(rb_tag)::value;
+            const size_t bytes = (size_t)RB * (W + 2) * sizeof(unsigned);
+            if (bytes > 64 * 1024)
+                PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)edt_row_kernel<Epi, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            PCSEG_LAUNCH((edt_row_kernel<Epi, RB>), dim3((H + RB - 1) / RB, B), dim3(256), bytes, s, ws.bits, ws.up, ws.dn, ws.any_bg, epi,
+                         count, H, W, ws.nch);
+            return PCSEG_OK;
+        };
+        const size_t per_row = (size_t)(W + 2) * sizeof(unsigned);
+        int rc;
+        if (8 * per_row <= 64 * 1024) rc = launch_rows(std::integral_constant<int, 8>());
+        else if (4 * per_row <= 160 * 1024) rc = launch_rows(std::integral_constant<int, 4>());
+        else rc = launch_rows(std::integral_constant<int, 1>());
+        if (rc) return rc;
     }
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
