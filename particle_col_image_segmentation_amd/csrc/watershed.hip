@@ -143,18 +143,23 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
         uint2 lv[WS_BATCH];
 #pragma unroll
         for (int j = 0; j < WS_BATCH; ++j) lv[j] = sLV[base + j * STEP];
+        // the running values come from registers alone; the LDS updates of a batch are skipped as a whole when no lane
+        // lowered anything in it (late iterations, converged neighbourhoods): one ballot instead of eight atomics
+        unsigned nw[WS_BATCH];
+        unsigned batch_diff = 0;
 #pragma unroll
         for (int j = 0; j < WS_BATCH; ++j) {
-            unsigned cur = lv[j].x;
-            const unsigned cand = max(lv[j].y, prev);
-            // unconditional LDS atomic min: nothing under an exec mask on the dependency chain (a compare + masked
-            // store + masked move per step cost 10 % more), and still monotone when another wave lowered the cell
-            // since the batch was read
-            atomicMin(&sLw[2 * (base + j * STEP)], cand);
-            const unsigned nw = min(cur, cand);
-            diff |= cur ^ nw;
-            cur = nw;
-            prev = cur;
+            const unsigned cur = lv[j].x;
+            nw[j] = min(cur, max(lv[j].y, prev));
+            batch_diff |= cur ^ nw[j];
+            prev = nw[j];
+        }
+        if (__any(batch_diff != 0)) {
+            // unconditional LDS atomic min per cell: nothing under an exec mask (a compare + masked store per step cost
+            // 10 % more), and still monotone when another wave lowered the cell since the batch was read
+#pragma unroll
+            for (int j = 0; j < WS_BATCH; ++j) atomicMin(&sLw[2 * (base + j * STEP)], nw[j]);
+            diff |= batch_diff;
         }
     }
     return diff != 0;
