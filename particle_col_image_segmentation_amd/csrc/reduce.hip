@@ -232,18 +232,29 @@ __global__ void __launch_bounds__(256) region_reduce_col_kernel(const int *__res
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int k = 0; k < (NC > 0 ? NC : 1); ++k) acc[j][k] = 0.0;
-        for (int r = r0; r <= r1; ++r) {
-            int4 l4 = make_int4(0, 0, 0, 0);
-            float4 v[NC > 0 ? NC : 1];
+        // the next row's six 16-byte loads are issued before this row is processed (the run logic below is a chain of
+        // branches the compiler does not move loads across)
+        int4 l4n = make_int4(0, 0, 0, 0);
+        float4 vn[NC > 0 ? NC : 1];
+        auto fetch = [&](int r) {
+            l4n = make_int4(0, 0, 0, 0);
             if (r < r1) {
-                l4 = *reinterpret_cast<const int4 *>(lab + (int64_t)r * W + c);
+                l4n = *reinterpret_cast<const int4 *>(lab + (int64_t)r * W + c);
                 if (NC > 0) {
 #pragma unroll
                     for (int k = 0; k < NC; ++k)
-                        v[k] = k < C ? *reinterpret_cast<const float4 *>(pl + (int64_t)k * n + (int64_t)r * W + c)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                        vn[k] = k < C ? *reinterpret_cast<const float4 *>(pl + (int64_t)k * n + (int64_t)r * W + c)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
+        };
+        fetch(r0);
+        for (int r = r0; r <= r1; ++r) {
+            const int4 l4 = l4n;
+            float4 v[NC > 0 ? NC : 1];
+#pragma unroll
+            for (int k = 0; k < (NC > 0 ? NC : 1); ++k) v[k] = vn[k];
+            fetch(r + 1);
             const int ll[4] = {l4.x, l4.y, l4.z, l4.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
