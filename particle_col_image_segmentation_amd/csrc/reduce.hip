@@ -256,20 +256,51 @@ __global__ void __launch_bounds__(256) region_reduce_col_kernel(const int *__res
             for (int k = 0; k < (NC > 0 ? NC : 1); ++k) v[k] = vn[k];
             fetch(r + 1);
             const int ll[4] = {l4.x, l4.y, l4.z, l4.w};
+            if (r == r1) {
+                // end of the block: the four columns of a lane usually sit in the same region; folding them first
+                // quarters the number of same-slot LDS atomics the whole block fires at once
+                long long scol[4], rmin[4], rmax1[4], cmin[4], cmax[4], first[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    scol[j] = (long long)(c + j) * area[j];
+                    rmin[j] = start[j];
+                    rmax1[j] = start[j] + area[j];
+                    cmin[j] = cmax[j] = c + j;
+                    first[j] = (long long)start[j] * W + c + j;
+                }
+#pragma unroll
+                for (int j = 1; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < j; ++i)
+                        if (cur[j] > 0 && cur[j] == cur[i]) {
+                            area[i] += area[j]; srow[i] += srow[j]; scol[i] += scol[j];
+                            rmin[i] = min(rmin[i], rmin[j]); rmax1[i] = max(rmax1[i], rmax1[j]);
+                            cmin[i] = min(cmin[i], cmin[j]); cmax[i] = max(cmax[i], cmax[j]); first[i] = min(first[i], first[j]);
+#pragma unroll
+                            for (int k = 0; k < (NC > 0 ? NC : 1); ++k) acc[i][k] += acc[j][k];
+                            cur[j] = 0;
+                        }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (cur[j] > 0)
+                        region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, cur[j], area[j], srow[j], scol[j], rmin[j], rmax1[j],
+                                          cmin[j], cmax[j], first[j], acc[j]);
+                break;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (ll[j] != cur[j] || r == r1) {
+                if (ll[j] != cur[j]) {
                     if (cur[j] > 0)
                         region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, cur[j], area[j], srow[j], (long long)(c + j) * area[j],
                                           start[j], start[j] + area[j], c + j, c + j, (long long)start[j] * W + c + j, acc[j]);
-                    cur[j] = r < r1 ? ll[j] : 0;
+                    cur[j] = ll[j];
                     start[j] = r;
                     area[j] = 0;
                     srow[j] = 0;
 #pragma unroll
                     for (int k = 0; k < (NC > 0 ? NC : 1); ++k) acc[j][k] = 0.0;
                 }
-                if (r < r1 && ll[j] > 0) {
+                if (ll[j] > 0) {
                     area[j] += 1;
                     srow[j] += r;
                     if (NC > 0) {
