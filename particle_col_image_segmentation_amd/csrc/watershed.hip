@@ -193,7 +193,8 @@ struct WsTiling {
 __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool FIRST, unsigned *__restrict__ val,
                                                         unsigned *__restrict__ L, uint8_t *__restrict__ dirty_in,
                                                         uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed,
-                                                        int *__restrict__ any_marked, int H, int W, WsTiling cur, WsTiling nxt)
+                                                        int *__restrict__ any_marked, int H, int W, WsTiling cur, WsTiling nxt,
+                                                        int max_iter)
 {
     __shared__ uint2 sLV[WS_N];
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
@@ -240,7 +241,8 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
     const SweepLine ln = ws_line();
     const int wave = threadIdx.x >> 6;
     bool changed_any = false;
-    for (int iter = 0; iter < 100000; ++iter) {
+    bool capped = true;  // left before the tile's fixed point (round 0 stops after max_iter sweeps per direction)
+    for (int iter = 0; iter < max_iter; ++iter) {
         // one code path per direction: the step is a compile-time constant there, so the LDS addresses of a batch are
         // base + constant
         bool changed;
@@ -248,7 +250,7 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
         else if (wave == 1) changed = ws_sweep<-1>(sLV, ln.start);
         else if (wave == 2) changed = ws_sweep<WS_P>(sLV, ln.start);
         else changed = ws_sweep<-WS_P>(sLV, ln.start);
-        if (!__syncthreads_or(changed)) break;
+        if (!__syncthreads_or(changed)) { capped = false; break; }
         changed_any = true;
     }
     if (!FIRST && !changed_any) return;
@@ -261,8 +263,9 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
         const int lr = e < 4 ? (qy ? WS_T : 1) : qy * (WS_T / 2) + j + 1;
         const int lc = e < 4 ? qx * (WS_T / 2) + j + 1 : (qx ? WS_T : 1);
         const int r = r0 + lr - 1, c = c0 + lc - 1;
-        bool ch = false;
-        if (r >= 0 && r < H && c >= 0 && c < W)
+        // a tile that stopped early is not consistent inside: all four corner tiles have to look at it again
+        bool ch = capped;
+        if (!capped && r >= 0 && r < H && c >= 0 && c < W)
             ch = sLV[lr * WS_P + lc].x != (FIRST ? initial(r, c).x : L[fbase + (int64_t)r * W + c]);
         const unsigned long long half = (threadIdx.x & 32) ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
         if ((__ballot(ch) & half) && j == 0) {
@@ -1009,6 +1012,11 @@ static PollSlots *poll_slots()
     return &slots;
 }
 
+// Round 0 stops every tile after this many sweeps per direction: the round after it visits every tile anyway (with the
+// other tiling), so squeezing the last changes out of isolated tiles is wasted work; a tile cut short marks all four
+// corner tiles.  Measured on the benchmark batch: 16 -> 4.6 % less relaxation time than no limit, 8 -> 1 %, 6 -> none.
+constexpr int WS_ROUND0_SWEEPS = 16;
+
 static long long g_ws_counters[4] = {0, 0, 0, 0};  // [0] unused (lives on the device), relax launches, calls, -
 static unsigned long long *g_ws_dev_tiles[64] = {nullptr};  // per device: relaxation tiles processed since the last reset
 
@@ -1146,7 +1154,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         int rc = fixed_point(8, max_rounds, [&](int round, uint8_t *din, uint8_t *dout, int *any_marked) {
             const WsTiling &cur = tilings[round & 1], &nxt = tilings[(round + 1) & 1];
             PCSEG_LAUNCH(ws_relax_kernel, dim3(cur.nx, cur.ny, B), dim3(256), 0, s, inputs, round == 0, val, L, din, dout, changed,
-                         any_marked, H, W, cur, nxt);
+                         any_marked, H, W, cur, nxt, round == 0 ? WS_ROUND0_SWEEPS : 100000);
             ++relax_launches;
         });
         if (rc) return rc;
