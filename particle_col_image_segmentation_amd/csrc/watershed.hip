@@ -8,7 +8,8 @@
 // because every comparison that decides "a pops before b" for L(a) < L(b) is a
 // strict value comparison.  Hence the pixel that labels q (its first-popped
 // neighbour) has L = min over q's neighbours, and
-//   * parallel path: (1) L by tile-iterated relaxation, (2) labels by a
+//   * parallel path: (1) L by tile-iterated relaxation (rounds alternate
+//     between two half-tile-shifted tilings), (2) labels by a seed-first
 //     union-find over the links "pixel -- each neighbour with L == Lmin", (3) a
 //     proof condition: for every non-seed reachable pixel ALL neighbours with
 //     L == Lmin carry the pixel's label (equivalently: no union-find component
@@ -19,9 +20,8 @@
 //     same union-find on the refined keys;
 //   * frames that fail the check (equal-valued bottlenecks or seeds between two
 //     basins -- ubiquitous in quantised probability maps) are recomputed by an
-//     exact emulation of the reference's binary heap, one workgroup per frame.
+//     exact emulation of the reference's binary heap, one wave per frame.
 #include <type_traits>
-#include <vector>
 
 #include "common.h"
 
