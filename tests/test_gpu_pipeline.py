@@ -31,7 +31,8 @@ def _good_seeds(n, H, W, ct, start, ties=False):
     return seeds
 
 
-@pytest.mark.parametrize("H,W,ties", [(160, 192, False), (128, 128, True), (256, 256, False), (150, 201, False), (67, 130, True)])
+@pytest.mark.parametrize("H,W,ties", [(160, 192, False), (128, 128, True), (256, 256, False), (150, 201, False), (67, 130, True),
+                                      (97, 333, False), (320, 72, True), (200, 520, False), (64, 64, False), (33, 65, True)])
 def test_pipeline_matches_oracle(H, W, ties):
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible: the HIP path has no CPU fallback")
