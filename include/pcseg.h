@@ -157,7 +157,9 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
 
 /* ---- W1: skimage.segmentation.watershed(image, markers, mask=mask),
  * connectivity 1, no compactness, no watershed line (refine_boundaries.py:73).
- * [sync]  mode 0: parallel flood + proof check, frames that fail the check
+ * [sync]  (the host waits on the stream while the fixed points converge; on
+ * return the remaining work is queued on `stream`, not necessarily finished)
+ * mode 0: parallel flood + proof check, frames that fail the check
  * are re-run by the exact sequential priority flood; mode 1: exact sequential
  * flood for every frame; mode 2: parallel flood only (tie_flags tells which
  * frames are NOT proven exact); add 4 to also run the explicit per-pixel proof
@@ -165,8 +167,10 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
  * device int32[B] (may be NULL).
  * frame_stride: as for pcseg_edt_sq_lt_f32 (0 = H*W). */
 size_t pcseg_watershed_workspace_bytes(int B, int H, int W);
-/* measurement aid: out[0] = 64x64 tiles the minimax relaxation actually processed (dirty tiles over all rounds),
- * out[1] = relaxation launches, out[2] = watershed calls since the last reset (process-wide). */
+/* measurement aid: out[0] = 64x64 tiles the minimax relaxation actually processed (marked tiles over all rounds;
+ * kept in a counter on the current device and read with a blocking copy, i.e. after everything queued so far),
+ * out[1] = relaxation launches (including the speculative windows that find nothing to do), out[2] = watershed
+ * calls since the last reset (process-wide).  reset != 0 synchronises the device. */
 void pcseg_watershed_counters(int64_t *out, int reset);
 int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *markers, const uint8_t *mask,
                          int32_t *out, int32_t *tie_flags, int B, int H, int W, int mode,

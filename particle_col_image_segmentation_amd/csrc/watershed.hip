@@ -1003,7 +1003,10 @@ struct PollSlots {
 };
 static PollSlots *poll_slots()
 {
-    static thread_local PollSlots slots;
+    static thread_local PollSlots per_device[64];  // events belong to the device that was current when they were made
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    PollSlots &slots = per_device[dev];
     if (!slots.host) {
         if (hipHostMalloc((void **)&slots.host, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
         for (int i = 0; i < 2; ++i)
