@@ -176,10 +176,15 @@ class FramePipeline:
         res.update(ws_stats=ws_stats, ws_sums=ws_sums, ws_overflow=ws_overflow)
 
     # ------------------------------------------------------------------ host epilogue
-    def tables(self, res, frame_ids=None, ratios=RATIOS_5, distances=False, raster=19.0):
+    def tables(self, res, frame_ids=None, ratios=RATIOS_5, distances=False, raster=19.0, check=True):
         """Download one batch as numpy tables: ``cells`` (one row per cell / cluster region), ``rois`` (one row per
-        refined ROI), ``frames`` (one row per frame) and ``groups`` (one row per merged group)."""
-        res.check()
+        refined ROI), ``frames`` (one row per frame) and ``groups`` (one row per merged group).  ``check=False`` skips
+        ``BatchResult.check`` (a caller that has looked at the flags itself, e.g. to keep the ROI rows of a batch in
+        which the reference would have raised on one frame's cluster statistics)."""
+        if check:
+            res.check()
+        else:
+            res.synchronize()
         B, C, H, W = res["shape"]
         frame_ids = np.arange(B) if frame_ids is None else np.asarray(frame_ids)
         tb = self.tables_

@@ -128,3 +128,12 @@ def test_pipeline_reports_reference_crash():
     assert int(res["nan_flag"][0]) == 1
     with pytest.raises(ValueError, match="cannot convert float NaN to integer"):
         res.check()
+    # the refined ROIs do not depend on the failing statistic: a caller that has looked at the flag can still have them
+    pipe = FramePipeline(ct)
+    res = pipe.run(torch.from_numpy(st).cuda())
+    with pytest.raises(ValueError):
+        pipe.tables(res)
+    tabs = pipe.tables(res, check=False)
+    ref = orc.refine_boundaries(st[0, 3])
+    assert len(tabs["rois"]) == int(ref["labels"].max())
+
