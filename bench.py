@@ -42,13 +42,15 @@ KERNEL_BYTES_PER_PIXEL = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = 2 per core)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event table to stderr")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="host threads (each with its own stream pair) that consecutive batches alternate between")
     ap.add_argument("--serial", action="store_true",
                     help="profiling aid, not the headline: both kernel chains on one stream, so that per-kernel durations "
                          "are not inflated by the other chain's kernels sharing the CUs")
@@ -139,13 +141,13 @@ def _run(args):
     stack = synth.gen_batch_torch(10_000 + rank * B, B, H, W, dev)
     if args.levels > 0:
         stack[:, 3] = torch.round(stack[:, 3] * args.levels) / args.levels
-    pipe = FramePipeline(dict(synth.CELL_TYPES_5), overlap=not args.serial)
+    pipe = FramePipeline(dict(synth.CELL_TYPES_5), overlap=not args.serial, lanes=args.lanes)
     res = None
     # setup (not warmup): two priming passes so that torch's caching allocator holds every workspace block before the
     # W untimed warmup steps and the K timed steps
     for _ in range(2 + args.warmup):
         res = pipe.run(stack)
-    torch.cuda.synchronize()
+    pipe.synchronize()  # run() only hands the batch to a lane: drain the lanes, then torch.cuda.synchronize()
 
     def barrier():
         if use_dist:
@@ -158,7 +160,7 @@ def _run(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = pipe.run(stack)
-    torch.cuda.synchronize()
+    pipe.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     nbytes = lib.pcseg_timing_report(None, 0)

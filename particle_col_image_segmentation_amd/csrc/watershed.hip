@@ -21,6 +21,8 @@
 //   * frames that fail the check (equal-valued bottlenecks or seeds between two
 //     basins -- ubiquitous in quantised probability maps) are recomputed by an
 //     exact emulation of the reference's binary heap, one wave per frame.
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -1020,16 +1022,21 @@ static PollSlots *poll_slots()
 // corner tiles.  Measured on the benchmark batch: 16 -> 4.6 % less relaxation time than no limit, 8 -> 1 %, 6 -> none.
 constexpr int WS_ROUND0_SWEEPS = 16;
 
-static long long g_ws_counters[4] = {0, 0, 0, 0};  // [0] unused (lives on the device), relax launches, calls, -
+// the watershed may be called from several host threads at once (FramePipeline's lanes)
+static std::atomic<long long> g_ws_counters[4];  // [0] unused (lives on the device), relax launches, calls, -
 static unsigned long long *g_ws_dev_tiles[64] = {nullptr};  // per device: relaxation tiles processed since the last reset
+static std::mutex g_ws_dev_mutex;
 
 static unsigned long long *ws_dev_tiles()
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_ws_dev_mutex);
     if (!g_ws_dev_tiles[dev]) {
-        if (hipMalloc((void **)&g_ws_dev_tiles[dev], sizeof(unsigned long long)) != hipSuccess) return nullptr;
-        (void)hipMemset(g_ws_dev_tiles[dev], 0, sizeof(unsigned long long));
+        unsigned long long *p = nullptr;
+        if (hipMalloc((void **)&p, sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(p, 0, sizeof(unsigned long long));
+        g_ws_dev_tiles[dev] = p;
     }
     return g_ws_dev_tiles[dev];
 }
@@ -1043,14 +1050,14 @@ void pcseg_watershed_counters(int64_t *out, int reset)
         unsigned long long tiles = 0;
         if (dev) (void)hipMemcpy(&tiles, dev, sizeof(tiles), hipMemcpyDeviceToHost);  // blocking: waits for the work queued so far
         out[0] = (int64_t)tiles;
-        for (int i = 1; i < 4; ++i) out[i] = g_ws_counters[i];
+        for (int i = 1; i < 4; ++i) out[i] = g_ws_counters[i].load();
     }
     if (reset) {
         if (dev) {
             (void)hipDeviceSynchronize();
             (void)hipMemset(dev, 0, sizeof(unsigned long long));
         }
-        for (int i = 0; i < 4; ++i) g_ws_counters[i] = 0;
+        for (int i = 0; i < 4; ++i) g_ws_counters[i].store(0);
     }
 }
 

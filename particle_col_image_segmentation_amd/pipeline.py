@@ -37,7 +37,12 @@ class BatchResult(dict):
 
     def synchronize(self):
         pending, self._pending = self._pending, None
-        for ev in pending or ():
+        if pending is None:
+            return self
+        if hasattr(pending, "result"):  # a lane's future: (entries, closing events); re-raises what the lane raised
+            entries, pending = pending.result()
+            dict.update(self, entries)
+        for ev in pending:
             ev.synchronize()
         return self
 
@@ -73,7 +78,7 @@ class BatchResult(dict):
 
 class FramePipeline:
     def __init__(self, cell_types=None, threshold=0.5, boundary_plane=BOUNDARY_PLANE, cap=None, merged=True,
-                 watershed_mode=0, overlap=True):
+                 watershed_mode=0, overlap=True, lanes=2):
         self.cell_types = dict(cell_types or CELL_TYPES_5)
         self.tables_ = ops.ClassTables(self.cell_types, ta.CELL_TYPES, ta.MIN_CELL_AREA, ta.MIN_CLUSTER_AREA)
         self.threshold = float(threshold)
@@ -82,7 +87,10 @@ class FramePipeline:
         self.merged = merged
         self.watershed_mode = watershed_mode
         self.overlap = overlap
-        self._streams = None
+        self.lanes = max(1, int(lanes))
+        self._lane_pool = None  # one single-thread executor + stream pair per lane, made on first use
+        self._lane_streams = None
+        self._step = 0
 
     def run(self, stack):
         if stack.dim() != 4 or stack.dtype != torch.float32 or not stack.is_cuda:
@@ -94,28 +102,45 @@ class FramePipeline:
             self._class_chain(stack, res)
             self._refine_chain(stack, res)
             return res
-        # The class-map chain and the boundary-refinement chain only share the input.  The first is enqueued
-        # asynchronously on its own HIP stream; the second (whose relaxation polls the host) then runs on another, so
-        # the many short launches and polls of the watershed's late rounds overlap with the first chain's kernels.
-        cur = torch.cuda.current_stream()
-        if self._streams is None or self._streams[0].device != stack.device:
-            # the refinement chain is the critical path: its stream gets the higher priority
-            self._streams = (torch.cuda.Stream(device=stack.device, priority=0), torch.cuda.Stream(device=stack.device, priority=-1))
-        s1, s2 = self._streams
-        s1.wait_stream(cur)
-        s2.wait_stream(cur)
+        # The class-map chain and the boundary-refinement chain only share the input: each gets its own HIP stream (the
+        # refinement chain, whose fixed points poll the host, the higher priority).  Consecutive batches alternate between
+        # `lanes` host threads with a stream pair each, and `run` returns at once: while one batch sits in the
+        # latency-bound tail of its watershed (small launches, host round trips) the next batch's dense kernels keep the
+        # GPU busy.  The result object waits for its lane the first time an entry is read.
+        if self._lane_pool is None or self._lane_streams[0][0].device != stack.device:
+            from concurrent.futures import ThreadPoolExecutor
+            self._lane_pool = [ThreadPoolExecutor(max_workers=1, thread_name_prefix="pcseg-lane%d" % i) for i in range(self.lanes)]
+            self._lane_streams = [(torch.cuda.Stream(device=stack.device, priority=0), torch.cuda.Stream(device=stack.device, priority=-1))
+                                  for _ in range(self.lanes)]
+        lane = self._step % self.lanes
+        self._step += 1
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        res._pending = self._lane_pool[lane].submit(self._run_lane, lane, stack, ready, dict(res))
+        return res
+
+    def synchronize(self):
+        """Wait until every batch handed to ``run`` so far is finished (lanes drained, device idle)."""
+        for pool in self._lane_pool or ():
+            pool.submit(lambda: None).result()
+        torch.cuda.synchronize()
+
+    def _run_lane(self, lane, stack, ready, entries):
+        torch.cuda.set_device(stack.device)
+        out = BatchResult(entries)  # built privately: the caller's object only receives it on synchronize()
+        s1, s2 = self._lane_streams[lane]
+        s1.wait_event(ready)
+        s2.wait_event(ready)
         with torch.cuda.stream(s1):
-            self._class_chain(stack, res)
+            self._class_chain(stack, out)
         with torch.cuda.stream(s2):
-            self._refine_chain(stack, res)
-        # no host wait here: the result carries the two closing events (BatchResult.synchronize)
+            self._refine_chain(stack, out)
         done = (torch.cuda.Event(), torch.cuda.Event())
         done[0].record(s1)
         done[1].record(s2)
         stack.record_stream(s1)
         stack.record_stream(s2)
-        res._pending = done
-        return res
+        return dict(out), done
 
     def _class_chain(self, stack, res):
         B, C, H, W = stack.shape
