@@ -16,6 +16,7 @@ region) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a b
 target).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -164,10 +165,31 @@ def _run(args):
     barrier()
     elapsed = time.perf_counter() - t0
     nbytes = lib.pcseg_timing_report(None, 0)
-    import ctypes
     buf = ctypes.create_string_buffer(nbytes + 16)
     lib.pcseg_timing_report(buf, nbytes + 16)
     lib.pcseg_timing_enable(0)
+    timed_tiles = (ctypes.c_int64 * 4)()
+    lib.pcseg_watershed_counters(timed_tiles, 0)
+    # The same kernels once more with nothing beside them (2 steps, one stream, outside the timed region): in the timed
+    # region up to four streams share the CUs, so a launch's duration there says how the GPU was shared, not how good
+    # the kernel is.  Reported next to the timed-region figure as roofline.alone.
+    alone = None
+    if rank == 0 and not args.serial:
+        solo = FramePipeline(dict(synth.CELL_TYPES_5), overlap=False)
+        solo.run(stack)
+        torch.cuda.synchronize()
+        lib.pcseg_timing_enable(1)
+        lib.pcseg_watershed_counters(None, 1)
+        for _ in range(2):
+            solo.run(stack)
+        torch.cuda.synchronize()
+        n2 = lib.pcseg_timing_report(None, 0)
+        buf2 = ctypes.create_string_buffer(n2 + 16)
+        lib.pcseg_timing_report(buf2, n2 + 16)
+        lib.pcseg_timing_enable(0)
+        solo_tiles = (ctypes.c_int64 * 4)()
+        lib.pcseg_watershed_counters(solo_tiles, 0)
+        alone = (buf2.value.decode(), solo_tiles[0], solo_tiles[1], 2)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -199,18 +221,28 @@ def _run(args):
         bpp = KERNEL_BYTES_PER_PIXEL.get(short, float("nan"))
         avg_s = dom_ms / dom_calls / 1e3
         units = float(B * H * W)  # pixels one launch processes
-        if short == "ws_relax_kernel":
-            # the relaxation only touches dirty tiles: count the 64x64 tiles it really processed
-            cnt = (ctypes.c_int64 * 4)()
-            lib.pcseg_watershed_counters(cnt, 0)
-            if cnt[1]:
-                units = 4096.0 * cnt[0] / cnt[1]
+        def relax_bytes(tiles, launches, steps):
+            # the relaxation only touches marked tiles: count the 64x64 tiles it really processed; one launch per step is
+            # the set-up round, which reads the three inputs (9 B/px) and writes value keys, seed labels and levels
+            # (12 B/px) for every pixel instead of the 12 B/px of a plain round
+            return 12.0 * 4096.0 * tiles / launches + 9.0 * B * H * W * steps / launches
+
         launch_bytes = bpp * units
-        if short == "ws_relax_kernel":
-            # one launch per step is the set-up round: it reads the three inputs (9 B/px) and writes value keys, seed
-            # labels and levels (12 B/px) for every pixel instead of the 12 B/px of a plain round
-            launch_bytes += 9.0 * B * H * W * args.steps / dom_calls
+        if short == "ws_relax_kernel" and timed_tiles[1]:
+            units = 4096.0 * timed_tiles[0] / timed_tiles[1]
+            launch_bytes = relax_bytes(timed_tiles[0], dom_calls, args.steps)
         achieved = launch_bytes / avg_s / 1e9
+        alone_block = None
+        if alone is not None:
+            text, tiles, launches, steps2 = alone
+            for line in text.splitlines():
+                name, calls, ms = line.split("\t")
+                if name == dom_name:
+                    a_avg = float(ms) / int(calls) / 1e3
+                    a_bytes = relax_bytes(tiles, int(calls), steps2) if short == "ws_relax_kernel" else bpp * B * H * W
+                    alone_block = {"avg_launch_us": round(1e6 * a_avg, 2), "algorithmic_bytes_per_launch": round(a_bytes),
+                                   "achieved": round(a_bytes / a_avg / 1e9, 2), "frac": round(a_bytes / a_avg / 1e9 / HBM_PEAK_GBS, 5),
+                                   "how": "2 extra steps on one stream right after the timed region"}
         total_kernel_ms = sum(ms for _, ms in kernels.values())
         value = world * B * H * W * args.steps / elapsed / 1e6
         traffic = None
@@ -233,7 +265,7 @@ def _run(args):
                          "algorithmic_bytes_per_launch": round(launch_bytes),
                          "pixels_per_launch": round(units),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "alone": alone_block,
                          "share_of_kernel_time": round(dom_ms / total_kernel_ms, 4),
                          "chain_bytes_per_pixel": CHAIN_BYTES_PER_PIXEL,
                          "chain_achieved_GBps": round(CHAIN_BYTES_PER_PIXEL * value / world / 1e3, 3),
