@@ -476,79 +476,87 @@ __global__ void __launch_bounds__(256) ccl_flatten_kernel(int *__restrict__ pare
 }
 
 // ---- local maxima ----------------------------------------------------------
-// Both stencil passes stage a 64x16 tile with a 1-pixel halo in LDS (the 8 neighbour reads then hit LDS, and the
-// global read is one coalesced pass with 1.2x halo overhead instead of 9 cached loads per pixel).
-constexpr int LM_TW = 64, LM_TH = 16, LM_SW = LM_TW + 2, LM_SH = LM_TH + 2;
+// One stencil pass over a 64x16 tile staged in LDS with a 2-pixel halo: candidates (no higher 8-neighbour) are
+// determined for the tile and the ring around it, so the same pass can also tell which candidate pixels touch an
+// equal-valued NON-candidate -- the pixels that spoil their plateau.  That flag is left at the pixel's own slot of
+// `bad`; after the components of the candidates are known, locmax_propagate_kernel flattens the parents and raises
+// bad[root] for every flagged pixel (own-slot flags of non-root pixels are never read as root flags).
+constexpr int LM_TW = 64, LM_TH = 16, LM_SW = LM_TW + 4, LM_SH = LM_TH + 4, LM_CW = LM_TW + 2, LM_CH = LM_TH + 2;
 
-// candidate: no strictly higher 8-neighbour.  key = candidate ? value (0 mapped to INT_MIN) : 0.
 __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__restrict__ img, int *__restrict__ key,
-                                                                 int *__restrict__ nonconst, int H, int W)
+                                                                 uint8_t *__restrict__ bad, int *__restrict__ nonconst, int H, int W)
 {
     __shared__ int tile[LM_SH * LM_SW];
+    __shared__ uint8_t cand[LM_CH * LM_CW];  // tile + 1 ring: 0 inside and not a candidate, 1 candidate, 2 outside the image
     const int OUTSIDE = (int)0x80000000;  // image values are > INT_MIN by contract: never higher, never "different"
     const int r0 = blockIdx.y * LM_TH, c0 = blockIdx.x * LM_TW;
     const int64_t fbase = (int64_t)blockIdx.z * H * W;
     for (int i = threadIdx.x; i < LM_SH * LM_SW; i += 256) {
-        int r = r0 + i / LM_SW - 1, c = c0 + i % LM_SW - 1;
+        int r = r0 + i / LM_SW - 2, c = c0 + i % LM_SW - 2;
         tile[i] = (r >= 0 && r < H && c >= 0 && c < W) ? img[fbase + (int64_t)r * W + c] : OUTSIDE;
     }
     __syncthreads();
     bool any_differs = false;
-    for (int t = threadIdx.x; t < LM_TH * LM_TW; t += 256) {
-        const int lr = t / LM_TW, lc = t % LM_TW;
-        const int r = r0 + lr, c = c0 + lc;
-        if (r >= H || c >= W) continue;
+    for (int t = threadIdx.x; t < LM_CH * LM_CW; t += 256) {
+        const int lr = t / LM_CW, lc = t % LM_CW;  // ring coordinates: image pixel (r0 + lr - 1, c0 + lc - 1)
+        const int r = r0 + lr - 1, c = c0 + lc - 1;
         const int i = (lr + 1) * LM_SW + lc + 1;
         const int v = tile[i];
-        bool cand = true;
+        uint8_t state = 2;
+        if (r >= 0 && r < H && c >= 0 && c < W) {
+            bool is_cand = true, differs = false;
 #pragma unroll
-        for (int dr = -1; dr <= 1; ++dr)
+            for (int dr = -1; dr <= 1; ++dr)
 #pragma unroll
-            for (int dc = -1; dc <= 1; ++dc) {
-                if (dr == 0 && dc == 0) continue;
-                const int q = tile[i + dr * LM_SW + dc];
-                cand = cand && (q <= v);
-                any_differs = any_differs || (q != v && q != OUTSIDE);
-            }
-        // key must be non-zero for candidates and equal exactly when the values are equal (values > INT_MIN)
-        key[fbase + (int64_t)r * W + c] = cand ? (v == 0 ? (int)0x80000000 : v) : 0;
-    }
-    if (__any(any_differs) && lane_id() == 0 && nonconst[blockIdx.z] == 0) nonconst[blockIdx.z] = 1;
-}
-
-// bad[root] = 1 if any candidate of the component touches an equal-valued non-candidate
-__global__ void __launch_bounds__(256) locmax_bad_kernel(const int *__restrict__ img, const int *__restrict__ key,
-                                                          const int *__restrict__ parent, uint8_t *__restrict__ bad, int H, int W)
-{
-    __shared__ int tile[LM_SH * LM_SW];
-    __shared__ uint8_t noncand[LM_SH * LM_SW];  // inside the image and not a candidate
-    const int r0 = blockIdx.y * LM_TH, c0 = blockIdx.x * LM_TW;
-    const int64_t fbase = (int64_t)blockIdx.z * H * W;
-    for (int i = threadIdx.x; i < LM_SH * LM_SW; i += 256) {
-        int r = r0 + i / LM_SW - 1, c = c0 + i % LM_SW - 1;
-        bool in = r >= 0 && r < H && c >= 0 && c < W;
-        tile[i] = in ? img[fbase + (int64_t)r * W + c] : 0;
-        noncand[i] = in && key[fbase + (int64_t)r * W + c] == 0;
+                for (int dc = -1; dc <= 1; ++dc) {
+                    if (dr == 0 && dc == 0) continue;
+                    const int q = tile[i + dr * LM_SW + dc];
+                    is_cand = is_cand && (q <= v);
+                    differs = differs || (q != v && q != OUTSIDE);
+                }
+            state = is_cand ? 1 : 0;
+            if (lr >= 1 && lr <= LM_TH && lc >= 1 && lc <= LM_TW) any_differs = any_differs || differs;
+        }
+        cand[t] = state;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < LM_TH * LM_TW; t += 256) {
         const int lr = t / LM_TW, lc = t % LM_TW;
         const int r = r0 + lr, c = c0 + lc;
         if (r >= H || c >= W) continue;
-        const int i = (lr + 1) * LM_SW + lc + 1;
-        if (noncand[i]) continue;
+        const int i = (lr + 2) * LM_SW + lc + 2, j = (lr + 1) * LM_CW + lc + 1;
         const int v = tile[i];
+        const bool is_cand = cand[j] == 1;
         bool touches = false;
+        if (is_cand) {
 #pragma unroll
-        for (int dr = -1; dr <= 1; ++dr)
+            for (int dr = -1; dr <= 1; ++dr)
 #pragma unroll
-            for (int dc = -1; dc <= 1; ++dc) {
-                if (dr == 0 && dc == 0) continue;
-                const int j = i + dr * LM_SW + dc;
-                touches = touches || (noncand[j] && tile[j] == v);
-            }
-        if (touches) bad[fbase + parent[fbase + (int64_t)r * W + c]] = 1;
+                for (int dc = -1; dc <= 1; ++dc) {
+                    if (dr == 0 && dc == 0) continue;
+                    touches = touches || (cand[j + dr * LM_CW + dc] == 0 && tile[i + dr * LM_SW + dc] == v);
+                }
+        }
+        // key must be non-zero for candidates and equal exactly when the values are equal (values > INT_MIN)
+        key[fbase + (int64_t)r * W + c] = is_cand ? (v == 0 ? (int)0x80000000 : v) : 0;
+        bad[fbase + (int64_t)r * W + c] = touches ? 1 : 0;
     }
+    if (__any(any_differs) && lane_id() == 0 && nonconst[blockIdx.z] == 0) nonconst[blockIdx.z] = 1;
+}
+
+// flatten the candidates' parents and move every pixel's own flag to its root
+__global__ void __launch_bounds__(256) locmax_propagate_kernel(int *__restrict__ parent, uint8_t *bad, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t fbase = (int64_t)blockIdx.y * n;
+    int *par = parent + fbase;
+    int p = par[i];
+    if (p < 0) return;
+    int x = p, q;
+    while ((q = par[x]) != x) x = q;
+    if (x != p) par[i] = x;
+    if (x != (int)i && bad[fbase + i]) bad[fbase + x] = 1;
 }
 
 __global__ void __launch_bounds__(256) locmax_out_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ bad,
@@ -729,16 +737,13 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
         return PCSEG_ERR_WORKSPACE;
     }
     PCSEG_CHECK_HIP(hipMemsetAsync(nonconst, 0, sizeof(int) * B, s));
-    PCSEG_CHECK_HIP(hipMemsetAsync(bad, 0, (size_t)B * n, s));
     dim3 g2((W + LM_TW - 1) / LM_TW, (H + LM_TH - 1) / LM_TH, B);
-    PCSEG_LAUNCH(locmax_candidates_kernel, g2, dim3(256), 0, s, img, key, nonconst, H, W);
+    PCSEG_LAUNCH(locmax_candidates_kernel, g2, dim3(256), 0, s, img, key, bad, nonconst, H, W);  // writes every slot of `bad`
     PCSEG_CHECK_LAUNCH();
     int rc = ccl_roots<KeyI32, true>(KeyI32{key, W, (int64_t)H * W}, ws.parent, B, H, W, s);
     if (rc) return rc;
     dim3 g1((unsigned)((n + 255) / 256), B);
-    PCSEG_LAUNCH(ccl_flatten_kernel, g1, dim3(256), 0, s, ws.parent, n);
-    PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(locmax_bad_kernel, g2, dim3(256), 0, s, img, key, ws.parent, bad, H, W);
+    PCSEG_LAUNCH(locmax_propagate_kernel, g1, dim3(256), 0, s, ws.parent, bad, n);
     PCSEG_CHECK_LAUNCH();
     if (is_max) {
         PCSEG_LAUNCH(locmax_out_kernel, g1, dim3(256), 0, s, ws.parent, bad, nonconst, is_max, n);
