@@ -36,7 +36,7 @@ KERNEL_BYTES_PER_PIXEL = {
     "edt_row_kernel": 4.0, "edt_reach_kernel": 2.0,
     "ws_init_kernel": 21.0, "ws_relax_kernel": 12.0, "ws_k2_relax_kernel": 12.0, "ws_uf_tile_kernel": 13.0,
     "ws_uf_border_kernel": 0.0, "ws_uf_label_kernel": 12.0, "ws_uf_label4_kernel": 12.0, "ws_check_kernel": 8.0,
-    "ws_exact_kernel": 21.0, "locmax_candidates_kernel": 8.0, "locmax_bad_kernel": 8.0,
+    "ws_exact_kernel": 21.0, "locmax_candidates_kernel": 9.0, "locmax_propagate_kernel": 5.0,
 }
 
 
