@@ -137,3 +137,26 @@ def test_pipeline_reports_reference_crash():
     ref = orc.refine_boundaries(st[0, 3])
     assert len(tabs["rois"]) == int(ref["labels"].max())
 
+
+def test_batches_in_flight_do_not_interfere():
+    """Six different batches handed to one pipeline before any result is read (two lanes, so two are in flight at any
+    time and their kernels interleave on four streams) against the same batches run one by one on a single stream."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from particle_col_image_segmentation_amd import synth
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline
+    ct = dict(synth.CELL_TYPES_5)
+    batches = [torch.from_numpy(synth.gen_batch(7000 + 10 * k, 6, 192, 256, ties=(k % 3 == 2))).cuda() for k in range(6)]
+    pipe = FramePipeline(ct)
+    in_flight = [pipe.run(st) for st in batches]
+    solo = FramePipeline(ct, overlap=False)
+    keys = ("denoised", "labels", "counts", "stats", "recreated", "overlap_area", "markers", "n_markers", "ws_labels",
+            "tie_flags", "ws_stats", "kind", "cells", "nan_flag")
+    for st, res in zip(batches, in_flight):
+        ref = solo.run(st)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(res[k], ref[k]), k
+        np.testing.assert_allclose(res["ws_sums"].cpu().numpy(), ref["ws_sums"].cpu().numpy(), rtol=1e-9, atol=1e-9)
+    pipe.synchronize()
+
