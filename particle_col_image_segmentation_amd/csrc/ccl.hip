@@ -9,11 +9,14 @@
 // Because the root of a component is its raster-first pixel, skimage's label
 // numbering is the rank of the root among all roots: wave ballot/popcount +
 // block scan + one exclusive scan of the block totals.
+#include <type_traits>
+
 #include "common.h"
 
 namespace pcseg {
 
 constexpr int CCL_TW = 64, CCL_TH = 32, CCL_TILE = CCL_TW * CCL_TH;
+static_assert(CCL_TH == 32 && CCL_TW == 64, "the tile pass assumes one 64-lane row per trip and one 32-row bit word per column");
 constexpr int SCAN_PIX = 1024;  // pixels per block in the count / assign / relabel passes
 
 // ---- key functors: key(b, r, c) of pixel (r, c) of frame b; 0 = background, equal non-zero keys connect
@@ -63,9 +66,20 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(KeyFn keyfn, int *__restr
     __shared__ int par[CCL_TILE];
     const int b = blockIdx.z, r0 = blockIdx.y * CCL_TH, c0 = blockIdx.x * CCL_TW;
     const int64_t fbase = (int64_t)b * H * W;
-    for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
-        int r = r0 + i / CCL_TW, c = c0 + i % CCL_TW;
-        key[i] = (r < H && c < W) ? keyfn(b, r, c) : 0;
+    if constexpr (std::is_same<KeyFn, KeyBits>::value) {
+        // the tile's 32 rows are exactly one bit word per column, and a thread's pixels (i = tid + 256 k) all sit in
+        // column tid % 64: one load instead of eight
+        const int lc = threadIdx.x % CCL_TW, c = c0 + lc;
+        const unsigned word = c < W ? keyfn.words[((int64_t)b * keyfn.nch + (r0 >> 5)) * W + c] : 0u;
+        for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
+            const int lr = i / CCL_TW;
+            key[i] = (r0 + lr < H) ? (int)((word >> lr) & 1u) : 0;
+        }
+    } else {
+        for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
+            int r = r0 + i / CCL_TW, c = c0 + i % CCL_TW;
+            key[i] = (r < H && c < W) ? keyfn(b, r, c) : 0;
+        }
     }
     __syncthreads();
     // row runs are pre-linked without atomics: a wave covers one 64-pixel tile row per trip (CCL_TW == 64), run heads

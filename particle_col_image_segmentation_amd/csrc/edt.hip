@@ -211,26 +211,33 @@ __global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict
     const int kmax = epi.kmax(W);
     const int64_t fbase = (int64_t)b * H * W;
     unsigned long long cnt = 0;
-    for (int idx = threadIdx.x; idx < nrows * W; idx += 256) {
-        const int j = idx / W, c = idx % W;
+    // a thread takes two neighbouring pixels: their candidate columns overlap (ten LDS reads per trip serve sixteen
+    // candidates) and the two min chains are independent
+    const int pairs_per_row = (W + 1) / 2;
+    for (int idx = threadIdx.x; idx < nrows * pairs_per_row; idx += 256) {
+        const int j = idx / pairs_per_row, c = (idx % pairs_per_row) * 2;
         const int64_t gi = fbase + (int64_t)(r0 + j) * W + c;
         const unsigned *gr = g2 + j * P + 1;  // gr[-1] and gr[W] are the guard cells
-        unsigned best = gr[c];
-        for (int k = 1; k <= kmax && (unsigned)(k * k) < best; k += 4) {
-            if (c - k < 0 && c + k >= W) break;
-            unsigned gl[4], gq[4];
+        const bool two = c + 1 < W;
+        unsigned best0 = gr[c], best1 = two ? gr[c + 1] : 0u;
+        for (int k = 1; k <= kmax && (unsigned)(k * k) < max(best0, best1); k += 4) {
+            if (c + 1 - k < 0 && c + k >= W) break;
+            // columns c-k-3 .. c-k+1 on the left, c+k .. c+k+4 on the right
+            unsigned gl[5], gq[5];
 #pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) {
-                gl[j2] = gr[max(c - k - j2, -1)];
-                gq[j2] = gr[min(c + k + j2, W)];
+            for (int t = 0; t < 5; ++t) {
+                gl[t] = gr[max(c - k + 1 - t, -1)];
+                gq[t] = gr[min(c + k + t, W)];
             }
 #pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) {
-                const unsigned kk = (unsigned)((k + j2) * (k + j2));
-                best = min(best, min(gl[j2], gq[j2]) + kk);
+            for (int t = 0; t < 4; ++t) {
+                const unsigned kk = (unsigned)((k + t) * (k + t));
+                best0 = min(best0, min(gl[t + 1], gq[t]) + kk);      // pixel c:     c-(k+t), c+(k+t)
+                best1 = min(best1, min(gl[t], gq[t + 1]) + kk);      // pixel c + 1: c+1-(k+t), c+1+(k+t)
             }
         }
-        epi.store(gi, best >= EDT_D2_INF ? (1ll << 40) : (long long)best, anybg, r0 + j, c, cnt);
+        epi.store(gi, best0 >= EDT_D2_INF ? (1ll << 40) : (long long)best0, anybg, r0 + j, c, cnt);
+        if (two) epi.store(gi + 1, best1 >= EDT_D2_INF ? (1ll << 40) : (long long)best1, anybg, r0 + j, c + 1, cnt);
     }
     if (count) {
         for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
