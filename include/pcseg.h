@@ -100,6 +100,12 @@ int pcseg_region_reduce(const int32_t *labels, const uint8_t *cls, const float *
 int pcseg_region_reduce_n(const int32_t *labels, const int32_t *counts, const uint8_t *cls, const float *planes,
                           int C, int B, int H, int W, int cap, int64_t *stats, uint8_t *cls_out, double *sums,
                           int32_t *overflow, pcseg_stream_t stream);
+/* same, with the plane sums restricted to the pixels whose class-map value is in sum_class_bits (bit v = value v,
+ * v < 64; 0 = every pixel): the regions of the other classes keep sums of 0 and their planes are not read.  The
+ * reference only ever sums isotopes over cell ROIs (tiff_analysis.py:1041-1044). */
+int pcseg_region_reduce_sel(const int32_t *labels, const int32_t *counts, const uint8_t *cls, uint64_t sum_class_bits,
+                            const float *planes, int C, int B, int H, int W, int cap, int64_t *stats,
+                            uint8_t *cls_out, double *sums, int32_t *overflow, pcseg_stream_t stream);
 
 /* ---- R1: binary_mask = boundary_map < threshold (refine_boundaries.py:44-45) */
 int pcseg_threshold_lt_f32(const float *img, float threshold, uint8_t *mask, int B, int H, int W,

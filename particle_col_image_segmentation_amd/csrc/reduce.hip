@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(256) region_init_kernel(long long *__restrict_
 
 template <bool HAS_PLANES>
 __global__ void __launch_bounds__(256) region_reduce_kernel(const int *__restrict__ labels, const float *__restrict__ planes,
-                                                             int C, int H, int W, int cap, long long *__restrict__ stats,
+                                                             const uint8_t *__restrict__ cls, unsigned long long sel, int C, int H,
+                                                             int W, int cap, long long *__restrict__ stats,
                                                              double *__restrict__ sums, int *__restrict__ overflow)
 {
     __shared__ int tags[RED_SLOTS];
@@ -65,8 +66,14 @@ __global__ void __launch_bounds__(256) region_reduce_kernel(const int *__restric
         const int l = inb ? lab[(int64_t)r * W + c] : 0;
         float v[RED_MAXC];
         if (HAS_PLANES) {
+            // sel != 0: plane sums only where the class map holds one of the selected values
+            bool want = inb && l > 0;
+            if (want && sel) {
+                const unsigned cv = cls[(int64_t)b * n + (int64_t)r * W + c];
+                want = cv < 64 && ((sel >> cv) & 1ull);
+            }
 #pragma unroll
-            for (int k = 0; k < RED_MAXC; ++k) v[k] = (k < C && inb && l > 0) ? pl[(int64_t)k * n + (int64_t)r * W + c] : 0.f;
+            for (int k = 0; k < RED_MAXC; ++k) v[k] = (k < C && want) ? pl[(int64_t)k * n + (int64_t)r * W + c] : 0.f;
         }
         const int lprev = __shfl_up(l, 1);
         const bool head = (lane == 0) || (l != lprev);
@@ -201,7 +208,8 @@ constexpr int COL_ROWS = 32;
 
 template <int NC>
 __global__ void __launch_bounds__(256) region_reduce_col_kernel(const int *__restrict__ labels, const float *__restrict__ planes,
-                                                                 int C, int H, int W, int cap, long long *__restrict__ stats,
+                                                                 const uint8_t *__restrict__ cls, unsigned long long sel, int C,
+                                                                 int H, int W, int cap, long long *__restrict__ stats,
                                                                  double *__restrict__ sums, int *__restrict__ overflow)
 {
     __shared__ int tags[RED_SLOTS];
@@ -236,21 +244,35 @@ __global__ void __launch_bounds__(256) region_reduce_col_kernel(const int *__res
         // branches the compiler does not move loads across)
         int4 l4n = make_int4(0, 0, 0, 0);
         float4 vn[NC > 0 ? NC : 1];
+        // sel != 0: plane sums only where the class map holds one of the selected values -- the planes of a 4-pixel
+        // group without such a pixel are not even read (for class-map components only cell regions need sums, and they
+        // are a small part of a frame)
+        unsigned wantn = 0xF;
         auto fetch = [&](int r) {
             l4n = make_int4(0, 0, 0, 0);
             if (r < r1) {
                 l4n = *reinterpret_cast<const int4 *>(lab + (int64_t)r * W + c);
                 if (NC > 0) {
+                    if (sel) {
+                        const unsigned cw = *reinterpret_cast<const unsigned *>(cls + (int64_t)b * n + (int64_t)r * W + c);
+                        wantn = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned cv = (cw >> (8 * j)) & 255u;
+                            if (cv < 64 && ((sel >> cv) & 1ull)) wantn |= 1u << j;
+                        }
+                    }
 #pragma unroll
                     for (int k = 0; k < NC; ++k)
-                        vn[k] = k < C ? *reinterpret_cast<const float4 *>(pl + (int64_t)k * n + (int64_t)r * W + c)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                        vn[k] = (k < C && wantn) ? *reinterpret_cast<const float4 *>(pl + (int64_t)k * n + (int64_t)r * W + c)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         };
         fetch(r0);
         for (int r = r0; r <= r1; ++r) {
             const int4 l4 = l4n;
+            const unsigned want = wantn;
             float4 v[NC > 0 ? NC : 1];
 #pragma unroll
             for (int k = 0; k < (NC > 0 ? NC : 1); ++k) v[k] = vn[k];
@@ -303,7 +325,7 @@ __global__ void __launch_bounds__(256) region_reduce_col_kernel(const int *__res
                 if (ll[j] > 0) {
                     area[j] += 1;
                     srow[j] += r;
-                    if (NC > 0) {
+                    if (NC > 0 && ((want >> j) & 1u)) {
 #pragma unroll
                         for (int k = 0; k < NC; ++k) {
                             const float4 f = v[k];
@@ -635,7 +657,16 @@ int pcseg_region_reduce_n(const int32_t *labels, const int32_t *counts, const ui
                           int B, int H, int W, int cap, int64_t *stats, uint8_t *cls_out, double *sums, int32_t *overflow,
                           pcseg_stream_t stream)
 {
+    return pcseg_region_reduce_sel(labels, counts, cls, 0, planes, C, B, H, W, cap, stats, cls_out, sums, overflow, stream);
+}
+
+int pcseg_region_reduce_sel(const int32_t *labels, const int32_t *counts, const uint8_t *cls, uint64_t sum_class_bits,
+                            const float *planes, int C, int B, int H, int W, int cap, int64_t *stats, uint8_t *cls_out,
+                            double *sums, int32_t *overflow, pcseg_stream_t stream)
+{
     PCSEG_REQUIRE(labels && stats && cap >= 1 && check_shape(B, H, W), "bad arguments");
+    PCSEG_REQUIRE(sum_class_bits == 0 || (cls && planes), "a class selection needs the class map and planes");
+    const unsigned long long sel = sum_class_bits;
     PCSEG_REQUIRE((!planes && !sums) || (planes && sums && C >= 1 && C <= RED_MAXC), "planes/sums/C mismatch (C <= 8)");
     PCSEG_REQUIRE(!cls || cls_out, "cls needs cls_out");
     hipStream_t s = (hipStream_t)stream;
@@ -644,22 +675,23 @@ int pcseg_region_reduce_n(const int32_t *labels, const int32_t *counts, const ui
     PCSEG_LAUNCH(region_init_kernel, gi, dim3(256), 0, s, (long long *)stats, sums, counts, cap, C, H, W);
     PCSEG_CHECK_LAUNCH();
     dim3 grid((H + RED_ROWS - 1) / RED_ROWS, B);
-    const bool vec = (W % 4) == 0 && ((uintptr_t)labels % 16) == 0 && (!planes || ((uintptr_t)planes % 16) == 0);
+    const bool vec = (W % 4) == 0 && ((uintptr_t)labels % 16) == 0 && (!planes || ((uintptr_t)planes % 16) == 0) &&
+                     (!sel || ((uintptr_t)cls % 4) == 0);
     const dim3 cgrid((W / 4 + 255) / 256, (H + COL_ROWS - 1) / COL_ROWS, B);
     if (vec && planes && C <= 5)
-        PCSEG_LAUNCH(region_reduce_col_kernel<5>, cgrid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats, sums,
+        PCSEG_LAUNCH(region_reduce_col_kernel<5>, cgrid, dim3(256), 0, s, labels, planes, cls, sel, C, H, W, cap, (long long *)stats, sums,
                      overflow);
     else if (vec && planes)
-        PCSEG_LAUNCH(region_reduce_col_kernel<8>, cgrid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats, sums,
+        PCSEG_LAUNCH(region_reduce_col_kernel<8>, cgrid, dim3(256), 0, s, labels, planes, cls, sel, C, H, W, cap, (long long *)stats, sums,
                      overflow);
     else if (vec)
-        PCSEG_LAUNCH(region_reduce_col_kernel<0>, cgrid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats, sums,
+        PCSEG_LAUNCH(region_reduce_col_kernel<0>, cgrid, dim3(256), 0, s, labels, planes, cls, sel, C, H, W, cap, (long long *)stats, sums,
                      overflow);
     else if (planes)
-        PCSEG_LAUNCH(region_reduce_kernel<true>, grid, dim3(256), 0, s, labels, planes, C, H, W, cap, (long long *)stats,
+        PCSEG_LAUNCH(region_reduce_kernel<true>, grid, dim3(256), 0, s, labels, planes, cls, sel, C, H, W, cap, (long long *)stats,
                            sums, overflow);
     else
-        PCSEG_LAUNCH(region_reduce_kernel<false>, grid, dim3(256), 0, s, labels, planes, C, H, W, cap,
+        PCSEG_LAUNCH(region_reduce_kernel<false>, grid, dim3(256), 0, s, labels, planes, cls, sel, C, H, W, cap,
                            (long long *)stats, sums, overflow);
     PCSEG_CHECK_LAUNCH();
     if (cls) {

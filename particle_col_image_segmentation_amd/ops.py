@@ -96,8 +96,9 @@ def compact_labels(roots):
     return labels, counts
 
 
-def region_reduce(labels, counts=None, cls=None, planes=None, cap=None):
-    """regionprops sums + optional class at first pixel + optional per-label plane sums.
+def region_reduce(labels, counts=None, cls=None, planes=None, cap=None, sum_classes=0):
+    """regionprops sums + optional class at first pixel + optional per-label plane sums.  ``sum_classes`` (bit v = class
+    value v; 0 = all): plane sums only over pixels of those classes -- the other regions keep 0 and cost no plane reads.
 
     Returns (stats int64 (B,cap,8), cls_out uint8 (B,cap) | None, sums float64 (B,cap,C) | None,
     overflow int32 (B,))."""
@@ -123,8 +124,10 @@ def region_reduce(labels, counts=None, cls=None, planes=None, cap=None):
         counts = _req(counts, torch.int32, 1)
     overflow = torch.zeros((B,), dtype=torch.int32, device=dev)
     lib = _lib.load()
-    _lib.check(lib.pcseg_region_reduce_n(_ptr(labels), _ptr(counts), _ptr(cls), _ptr(planes), C, B, H, W, cap,
-                                         _ptr(stats), _ptr(cls_out), _ptr(sums), _ptr(overflow), _stream()),
+    if sum_classes and (cls is None or planes is None):
+        raise ValueError("sum_classes needs cls and planes")
+    _lib.check(lib.pcseg_region_reduce_sel(_ptr(labels), _ptr(counts), _ptr(cls), int(sum_classes), _ptr(planes), C, B, H, W,
+                                           cap, _ptr(stats), _ptr(cls_out), _ptr(sums), _ptr(overflow), _stream()),
                "region_reduce")
     return stats, cls_out, sums, overflow
 

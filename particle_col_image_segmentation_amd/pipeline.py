@@ -76,6 +76,20 @@ class BatchResult(dict):
         return self
 
 
+_LANES = {}  # (device index, lanes) -> (executors, stream pairs): shared by every pipeline of the process
+
+
+def _lanes_for(device, lanes):
+    key = (device.index, lanes)
+    if key not in _LANES:
+        from concurrent.futures import ThreadPoolExecutor
+        pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix="pcseg-lane%d" % i) for i in range(lanes)]
+        streams = [(torch.cuda.Stream(device=device, priority=0), torch.cuda.Stream(device=device, priority=-1))
+                   for _ in range(lanes)]
+        _LANES[key] = (pools, streams)
+    return _LANES[key]
+
+
 class FramePipeline:
     def __init__(self, cell_types=None, threshold=0.5, boundary_plane=BOUNDARY_PLANE, cap=None, merged=True,
                  watershed_mode=0, overlap=True, lanes=2):
@@ -108,10 +122,7 @@ class FramePipeline:
         # latency-bound tail of its watershed (small launches, host round trips) the next batch's dense kernels keep the
         # GPU busy.  The result object waits for its lane the first time an entry is read.
         if self._lane_pool is None or self._lane_streams[0][0].device != stack.device:
-            from concurrent.futures import ThreadPoolExecutor
-            self._lane_pool = [ThreadPoolExecutor(max_workers=1, thread_name_prefix="pcseg-lane%d" % i) for i in range(self.lanes)]
-            self._lane_streams = [(torch.cuda.Stream(device=stack.device, priority=0), torch.cuda.Stream(device=stack.device, priority=-1))
-                                  for _ in range(self.lanes)]
+            self._lane_pool, self._lane_streams = _lanes_for(stack.device, self.lanes)
         lane = self._step % self.lanes
         self._step += 1
         ready = torch.cuda.Event()
@@ -152,7 +163,11 @@ class FramePipeline:
         res["denoised"] = z
         # ---- label + region table (+ isotope sums of the class components) (A2, A3, M1)
         labels, counts = ops.label_equal8(z)
-        stats, cls_out, cc_sums, overflow = ops.region_reduce(labels, counts, cls=z, planes=stack, cap=cap)
+        # isotope sums are only ever reported for cell / cluster regions: the planes are read under those classes only
+        cell_bits = 0
+        for v in tb.cell_values:
+            cell_bits |= 1 << int(v)
+        stats, cls_out, cc_sums, overflow = ops.region_reduce(labels, counts, cls=z, planes=stack, cap=cap, sum_classes=cell_bits)
         res.update(labels=labels, counts=counts, stats=stats, cls_out=cls_out, cc_sums=cc_sums, overflow=overflow)
         # ---- classification, cluster cell counts, region lists (A3 tail, A4)
         res.update(ops.classify_regions(stats, cls_out, counts, tb))
