@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) region_reduce_kernel(const int *__restric
                     if (HAS_PLANES)
 #pragma unroll
                         for (int k = 0; k < RED_MAXC; ++k)
-                            if (k < C) atomicAdd(&gsum[(int64_t)(l - 1) * C + k], acc[k]);
+                            if (k < C && acc[k] != 0.0) atomicAdd(&gsum[(int64_t)(l - 1) * C + k], acc[k]);
                 }
             }
         }
@@ -184,7 +184,7 @@ __device__ __forceinline__ void region_commit(const RegionSlots &ls, long long *
         atomic_min_i64(&ls.lstat[slot][7], first);
 #pragma unroll
         for (int k = 0; k < NC; ++k)
-            if (k < C) atomicAdd(&ls.lsum[slot][k], acc[k]);
+            if (k < C && acc[k] != 0.0) atomicAdd(&ls.lsum[slot][k], acc[k]);  // (regions outside the class selection sum to 0)
     } else {
         long long *t = gst + (int64_t)(l - 1) * 8;
         atomicAdd((unsigned long long *)&t[0], (unsigned long long)s_area);
@@ -197,7 +197,7 @@ __device__ __forceinline__ void region_commit(const RegionSlots &ls, long long *
         atomic_min_i64(&t[7], first);
 #pragma unroll
         for (int k = 0; k < NC; ++k)
-            if (k < C) atomicAdd(&gsum[(int64_t)(l - 1) * C + k], acc[k]);
+            if (k < C && acc[k] != 0.0) atomicAdd(&gsum[(int64_t)(l - 1) * C + k], acc[k]);
     }
 }
 
