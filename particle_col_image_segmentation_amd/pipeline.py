@@ -66,6 +66,26 @@ class BatchResult(dict):
             self.synchronize()
         return dict.values(self)
 
+    def keys(self):
+        if self._pending:
+            self.synchronize()
+        return dict.keys(self)
+
+    def __iter__(self):
+        if self._pending:
+            self.synchronize()
+        return dict.__iter__(self)
+
+    def __contains__(self, key):
+        if self._pending:
+            self.synchronize()
+        return dict.__contains__(self, key)
+
+    def __len__(self):
+        if self._pending:
+            self.synchronize()
+        return dict.__len__(self)
+
     def check(self):
         """Raise for the conditions the reference raises for / the tables cannot hold."""
         if int(self["overflow"].sum().item()) or int(self["ws_overflow"].sum().item()):
