@@ -14,9 +14,9 @@
  *     (torch tensors' data_ptr()); the library allocates nothing persistent;
  *   - scratch comes from a caller-provided workspace sized by the matching
  *     *_workspace_bytes(B, H, W) query (256-byte aligned device memory);
- *   - work is enqueued on `stream` (a hipStream_t); functions marked [sync]
- *     also wait on that stream because a host-side convergence loop drives
- *     them, every other function is asynchronous;
+ *   - work is enqueued on `stream` (a hipStream_t) and every compute entry point
+ *     returns without waiting for it: no hidden host synchronisation, fixed
+ *     points included (they finish in device-side tail kernels);
  *   - return value: PCSEG_OK or a negative pcseg_status; the message is in
  *     pcseg_last_error() (thread local);
  *   - there is no CPU fallback anywhere: without a HIP device every compute
@@ -107,6 +107,17 @@ int pcseg_region_reduce_sel(const int32_t *labels, const int32_t *counts, const 
                             const float *planes, int C, int B, int H, int W, int cap, int64_t *stats,
                             uint8_t *cls_out, double *sums, int32_t *overflow, pcseg_stream_t stream);
 
+/* ---- A2 + A3 (+ M1) in one call: label(z_slice) and its regionprops table (tiff_analysis.py:743, 746-773).
+ * The same results as pcseg_ccl8_equal_u8 followed by pcseg_region_reduce_sel(labels, counts, cls = in, ...), but the
+ * numbering pass and the reduction are one kernel: every pixel's label is decoded from its union-find root while the
+ * table is accumulated, the label image is written once and never read back.  Workspace:
+ * pcseg_label_regions_workspace_bytes. */
+size_t pcseg_label_regions_workspace_bytes(int B, int H, int W);
+int pcseg_label_regions_u8(const uint8_t *in, uint64_t sum_class_bits, const float *planes, int C, int32_t *labels,
+                           int32_t *counts, int B, int H, int W, int cap, int64_t *stats, uint8_t *cls_out,
+                           double *sums, int32_t *overflow, void *workspace, size_t workspace_bytes,
+                           pcseg_stream_t stream);
+
 /* ---- R1: binary_mask = boundary_map < threshold (refine_boundaries.py:44-45) */
 int pcseg_threshold_lt_f32(const float *img, float threshold, uint8_t *mask, int B, int H, int W,
                            pcseg_stream_t stream);
@@ -139,6 +150,15 @@ int pcseg_dilate_disk_u8(const uint8_t *in, uint64_t value_bits, int radius, uin
 size_t pcseg_dilate_ccl_workspace_bytes(int B, int H, int W);
 int pcseg_dilate_ccl_roots_u8(const uint8_t *in, uint64_t value_bits, int radius, int32_t *roots,
                               int B, int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+/* the same components WITHOUT a label image, for callers that only look the components up at a few pixels (the merge
+ * step reads them at the region centroids, tiff_analysis.py:844-847): dilated_bits = the dilated mask as 32-row column
+ * words, uint32 (B, ceil(H/32), W), bit j of word (ch, c) = pixel (32 ch + j, c); run_parent = union-find over the
+ * vertical runs of set bits, int32 (B, H, W) of which ONLY the entries at the top pixel of each run (within its word)
+ * are written and meaningful.  Feeds pcseg_merge_groups_runs. */
+size_t pcseg_dilate_ccl_runs_workspace_bytes(int B, int H, int W);
+int pcseg_dilate_ccl_runs_u8(const uint8_t *in, uint64_t value_bits, int radius, uint32_t *dilated_bits,
+                             int32_t *run_parent, int B, int H, int W, void *workspace, size_t workspace_bytes,
+                             pcseg_stream_t stream);
 
 /* ---- A8: fill_particle_area (tiff_analysis.py:982-1015) in one pass pair:
  * out = ds with overlap pixels set to overlap_label, where overlap =
@@ -163,8 +183,9 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
 
 /* ---- W1: skimage.segmentation.watershed(image, markers, mask=mask),
  * connectivity 1, no compactness, no watershed line (refine_boundaries.py:73).
- * [sync]  (the host waits on the stream while the fixed points converge; on
- * return the remaining work is queued on `stream`, not necessarily finished)
+ * Asynchronous like everything else: the two fixed points (minimax levels, second-level keys) run a fixed number
+ * of grid rounds and finish in one-block-per-frame tail kernels, the frames that need the second level / the exact
+ * flood are listed and counted on the device.
  * mode 0: parallel flood + proof check, frames that fail the check
  * are re-run by the exact sequential priority flood; mode 1: exact sequential
  * flood for every frame; mode 2: parallel flood only (tie_flags tells which
@@ -175,7 +196,7 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
 size_t pcseg_watershed_workspace_bytes(int B, int H, int W);
 /* measurement aid: out[0] = 64x64 tiles the minimax relaxation actually processed (marked tiles over all rounds;
  * kept in a counter on the current device and read with a blocking copy, i.e. after everything queued so far),
- * out[1] = relaxation launches (including the speculative windows that find nothing to do), out[2] = watershed
+ * out[1] = relaxation grid launches (including the rounds that find nothing marked), out[2] = watershed
  * calls since the last reset (process-wide).  reset != 0 synchronises the device. */
 void pcseg_watershed_counters(int64_t *out, int reset);
 int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *markers, const uint8_t *mask,
@@ -196,6 +217,11 @@ int pcseg_merge_groups(const int32_t *dilated_labels, int keys_are_roots, const 
                        const int32_t *region_list, const int32_t *n_list, int32_t *group_of, int32_t *n_groups,
                        int B, int H, int W, int cap, int list_cap, void *workspace, size_t workspace_bytes,
                        pcseg_stream_t stream);
+/* the same grouping on the run-based components of pcseg_dilate_ccl_runs_u8 (workspace: pcseg_merge_groups_workspace_bytes) */
+int pcseg_merge_groups_runs(const uint32_t *dilated_bits, const int32_t *run_parent, const int64_t *stats,
+                            const int32_t *region_list, const int32_t *n_list, int32_t *group_of, int32_t *n_groups,
+                            int B, int H, int W, int cap, int list_cap, void *workspace, size_t workspace_bytes,
+                            pcseg_stream_t stream);
 
 /* member sums of the groups: group_stats int64 (B, list_cap, 8) = area, sum_row,
  * sum_col, min_row, min_col, max_row+1, max_col+1, members (tiff_analysis.py:855-872) */
@@ -234,9 +260,44 @@ int pcseg_remove_overlapping(const uint8_t *dapi, const uint8_t *other, double t
                              int B, int H, int W, void *workspace, size_t workspace_bytes,
                              pcseg_stream_t stream);
 
-/* ---- X1 (north_star extension, no reference call site): 256-bin histogram of
- * each frame over its own [min, max] (device int64 (B,256), float32 (B,2)
- * lo/hi); the between-class-variance argmax is a 256-element host epilogue. */
+/* ---- per-ROI table output (SURVEY.md 8b output formats / 8e: what the ranks all-gather): the fixed-capacity
+ * per-frame tables of the calls above, compacted on the device into dense float64 row tables.
+ *   rois   (n, 5 + C + n_ratios)   frame, label, area, centroid_row, centroid_col, S_0.., ratios (.m:136-139 form:
+ *                                  S[num] / sum of S[den...]); one row per refined ROI that owns a pixel
+ *   cells  (n, 14 + C + n_ratios)  frame, label, class, kind (1 cell, 2 cluster), area, centroid (2), bbox (4), cells,
+ *                                  group, group_combined, S_0.., ratios; one row per cell / cluster region
+ *   groups (n, 11)                 frame, slot (4 = combined), group, area, centroid (2), bbox (4), members
+ *   frames int64 (B, 17)           n_labels, n_rois, particle_area, particle_area + overlap, tie_flag, then per
+ *                                  cell-type slot: present, count, area in pixels (tiff_analysis.py:1018-1038
+ *                                  before its two round(x, 5), which the host applies)
+ * pcseg_table_layout counts and scans (totals: device int64[3] = rows of rois, cells, groups); the caller reads the
+ * totals, allocates, and pcseg_table_write fills the tables.  Both asynchronous on `stream`; every pointer of the
+ * struct is a device pointer, group_of / n_groups / group_stats entries may be NULL (slot absent / merged = False). */
+typedef struct pcseg_table_inputs {
+    int32_t B, cap, C, n_ratios;
+    const int64_t *frame_ids;                                   /* (B) id written into column 0 */
+    const int32_t *counts; const int64_t *stats; const uint8_t *cls_out; const double *cc_sums;  /* class-map components */
+    const uint8_t *kind; const uint8_t *slot_of; const int32_t *cells;                            /* pcseg_classify_regions */
+    const int64_t *particle_area; const int64_t *overlap_area; const int64_t *type_stats; const int32_t *tie_flags;
+    const int32_t *region_list; const int32_t *n_list;          /* (B, 5, cap), (B, 5) */
+    const int32_t *group_of[5]; const int32_t *n_groups[5]; const int64_t *group_stats[5];       /* (B, cap), (B), (B, cap, 8) */
+    const int32_t *n_markers; const int64_t *ws_stats; const double *ws_sums;                     /* refined ROIs */
+    int32_t ratio_num[8]; int32_t ratio_den[8][4];              /* plane indices, -1 = unused */
+} pcseg_table_inputs;
+size_t pcseg_table_workspace_bytes(int B, int cap);
+int pcseg_table_layout(const pcseg_table_inputs *in, int64_t *totals, void *workspace, size_t workspace_bytes,
+                       pcseg_stream_t stream);
+int pcseg_table_write(const pcseg_table_inputs *in, double *rois, double *cells, double *groups, int64_t *frames,
+                      void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
+/* ---- X1 (north_star extension; refine_boundaries.py:22 imports skimage.filters and never calls it): the library
+ * SURVEY.md 8a names is the oracle -- skimage.filters.threshold_otsu(float32 image, nbins=256), pinned by
+ * tests/golden/extensions.npz.  pcseg_otsu_f32: threshold[b] (device float64 (B,), the value is the float32 bin
+ * centre the library returns; a constant frame returns its value), plus the histogram it was taken from: hist device
+ * int64 (B,256) over each frame's own [min, max] with numpy.histogram's float32 binning, lohi device float32 (B,2).
+ * Entirely on the device, asynchronous on `stream`.  pcseg_otsu_hist_f32: the histogram alone. */
+int pcseg_otsu_f32(const float *img, double *threshold, int64_t *hist, float *lohi, int B, int H, int W,
+                   pcseg_stream_t stream);
 int pcseg_otsu_hist_f32(const float *img, int64_t *hist, float *lohi, int B, int H, int W,
                         pcseg_stream_t stream);
 

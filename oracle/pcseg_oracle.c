@@ -390,11 +390,16 @@ void orc_watershed(const double *img, const int32_t *markers, const uint8_t *mas
 }
 
 /* ------------------------------------------------------------------ X1 ---
- * skimage.filters.threshold_otsu(image, nbins=256) -- north_star extension,
- * no reference call site (refine_boundaries.py:22 imports filters, never uses
- * it): PARITY UNPINNED BY THE REFERENCE; restated from scikit-image 0.18.3:
- * histogram over [min,max] with 256 equal bins, bin centres, between-class
- * variance maximised over the split index, threshold = centre of that bin.
+ * skimage.filters.threshold_otsu(image, nbins=256) on a float32 image -- north_star extension, no reference call
+ * site (refine_boundaries.py:22 imports filters, never uses it); the library itself is the oracle SURVEY.md 8a
+ * names, PINNED by tests/golden/extensions.npz (scikit-image 0.18.3 on numpy 1.26.4).  Restated step by step:
+ *   numpy.histogram(float32 image, 256): edges = float32(i * ((hi - lo) / 256) + lo) computed in float64
+ *   (linspace), last edge = hi; index = trunc(((x - lo) / (hi - lo)) * 256) in FLOAT32 arithmetic, 256 -> 255,
+ *   then one step down if x < edge[index], one step up if x >= edge[index + 1] (not for the last bin);
+ *   bin centres = (edge[i] + edge[i + 1]) / 2 in float32;
+ *   threshold_otsu: cumulative sums from the left (class 1) and from the RIGHT (class 2) in float64, sequential
+ *   like numpy.cumsum; variance[i] = (w1[i] * w2[i + 1]) * (mean1[i] - mean2[i + 1])^2; first maximum; the
+ *   threshold is the float32 centre of that bin.  A constant image returns its value.
  * hist[256] is returned for the caller's checks. */
 double orc_otsu_f32(const float *img, size_t n, int64_t *hist)
 {
@@ -402,37 +407,48 @@ double orc_otsu_f32(const float *img, size_t n, int64_t *hist)
     for (size_t i = 1; i < n; ++i) { if (img[i] < lo) lo = img[i]; if (img[i] > hi) hi = img[i]; }
     for (int b = 0; b < 256; ++b) hist[b] = 0;
     if (lo == hi) { hist[0] = (int64_t)n; return (double)lo; }
-    /* numpy.histogram: bin = floor((x - lo) / (hi - lo) * 256) in float64, with edge corrections */
-    double dlo = (double)lo, dhi = (double)hi, norm = 256.0 / (dhi - dlo);
+    float edges[257];
+    const double step = ((double)hi - (double)lo) / 256.0;
+    for (int i = 0; i < 257; ++i) {
+        volatile double prod = (double)i * step;  /* two roundings, like numpy's y * step; y += start */
+        edges[i] = (float)(prod + (double)lo);
+    }
+    edges[256] = hi;
+    const float denom = hi - lo;
     for (size_t i = 0; i < n; ++i) {
-        double x = (double)img[i];
-        int b = (int)((x - dlo) * norm);
-        if (b >= 256) b = 255;
-        /* numpy corrects indices against the float64 edges */
-        double e0 = dlo + (dhi - dlo) * ((double)b / 256.0);
-        double e1 = dlo + (dhi - dlo) * ((double)(b + 1) / 256.0);
-        if (x < e0 && b > 0) --b;
-        else if (x >= e1 && b < 255) ++b;
+        const float x = img[i];
+        volatile float q = (x - lo) / denom;
+        const float f = q * 256.0f;
+        int b = (int)f;
+        if (b == 256) b = 255;
+        if (x < edges[b]) --b;
+        if (x >= edges[b + 1] && b != 255) ++b;
         hist[b]++;
     }
-    double best = -1.0, thr = dlo;
-    double w1 = 0.0, s1 = 0.0, wt = 0.0, st = 0.0;
-    double centers[256];
+    float centers[256];
+    double p[256], cs1[256], cs2[256];
+    int64_t w1[256], w2[256];
     for (int b = 0; b < 256; ++b) {
-        double e0 = dlo + (dhi - dlo) * ((double)b / 256.0);
-        double e1 = dlo + (dhi - dlo) * ((double)(b + 1) / 256.0);
-        centers[b] = (e0 + e1) / 2.0;
-        wt += (double)hist[b]; st += (double)hist[b] * centers[b];
+        volatile float sum = edges[b] + edges[b + 1];
+        centers[b] = sum / 2.0f;
+        p[b] = (double)hist[b] * (double)centers[b];
     }
+    int64_t acc = 0;
+    double facc = 0.0;
+    for (int b = 0; b < 256; ++b) { acc += hist[b]; w1[b] = acc; facc += p[b]; cs1[b] = facc; }
+    acc = 0;
+    facc = 0.0;
+    for (int b = 255; b >= 0; --b) { acc += hist[b]; w2[b] = acc; facc += p[b]; cs2[b] = facc; }
+    double best = 0.0;
+    int arg = 0;
     for (int b = 0; b < 255; ++b) {
-        w1 += (double)hist[b]; s1 += (double)hist[b] * centers[b];
-        double w2 = wt - w1;
-        if (w1 == 0.0 || w2 == 0.0) continue;
-        double m1 = s1 / w1, m2 = (st - s1) / w2;
-        double var = w1 * w2 * (m1 - m2) * (m1 - m2);
-        if (var > best) { best = var; thr = centers[b]; }
+        const double m1 = cs1[b] / (double)w1[b], m2 = cs2[b + 1] / (double)w2[b + 1];
+        const double d = m1 - m2;
+        volatile double sq = d * d;
+        const double var = (double)(w1[b] * w2[b + 1]) * sq;
+        if (b == 0 || var > best) { best = var; arg = b; }
     }
-    return thr;
+    return (double)centers[arg];
 }
 
 /* ------------------------------------------------------------------ X2 ---

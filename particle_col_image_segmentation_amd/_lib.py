@@ -35,6 +35,8 @@ SIGNATURES = {
     "pcseg_region_reduce": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "pcseg_region_reduce_n": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "pcseg_region_reduce_sel": (c_int, [_P, _P, _P, ctypes.c_uint64, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "pcseg_label_regions_workspace_bytes": (c_size_t, [_I, _I, _I]),
+    "pcseg_label_regions_u8": (c_int, [_P, c_uint64, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, c_size_t, _P]),
     "pcseg_threshold_lt_f32": (c_int, [_P, c_float, _P, _I, _I, _I, _P]),
     "pcseg_edt_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_edt_sq_u8": (c_int, [_P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),
@@ -52,14 +54,34 @@ SIGNATURES = {
     "pcseg_merge_groups": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_dilate_ccl_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_dilate_ccl_roots_u8": (c_int, [_P, c_uint64, _I, _P, _I, _I, _I, _P, c_size_t, _P]),
+    "pcseg_dilate_ccl_runs_workspace_bytes": (c_size_t, [_I, _I, _I]),
+    "pcseg_dilate_ccl_runs_u8": (c_int, [_P, c_uint64, _I, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
+    "pcseg_merge_groups_runs": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_group_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "pcseg_classify_regions": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "pcseg_nearest_dist_f64": (c_int, [_P, _I, _P, _I, _P, _P]),
     "pcseg_overlap_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_remove_overlapping": (c_int, [_P, _P, c_double, _P, _I, _I, _I, _P, c_size_t, _P]),
+    "pcseg_table_workspace_bytes": (c_size_t, [_I, _I]),
+    "pcseg_table_layout": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "pcseg_table_write": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "pcseg_otsu_hist_f32": (c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "pcseg_otsu_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "pcseg_morph3x3": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
 }
+
+
+class TableInputs(ctypes.Structure):
+    """struct pcseg_table_inputs of include/pcseg.h, field for field."""
+    _fields_ = [("B", ctypes.c_int32), ("cap", ctypes.c_int32), ("C", ctypes.c_int32), ("n_ratios", ctypes.c_int32),
+                ("frame_ids", _P),
+                ("counts", _P), ("stats", _P), ("cls_out", _P), ("cc_sums", _P),
+                ("kind", _P), ("slot_of", _P), ("cells", _P),
+                ("particle_area", _P), ("overlap_area", _P), ("type_stats", _P), ("tie_flags", _P),
+                ("region_list", _P), ("n_list", _P),
+                ("group_of", _P * 5), ("n_groups", _P * 5), ("group_stats", _P * 5),
+                ("n_markers", _P), ("ws_stats", _P), ("ws_sums", _P),
+                ("ratio_num", ctypes.c_int32 * 8), ("ratio_den", (ctypes.c_int32 * 4) * 8)]
 
 
 def load():

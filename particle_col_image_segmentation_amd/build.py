@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["stencil.hip", "ccl.hip", "reduce.hip", "edt.hip", "watershed.hip"]
+SOURCES = ["stencil.hip", "ccl.hip", "reduce.hip", "edt.hip", "watershed.hip", "tables.hip"]
 LIB = os.path.join(HERE, "libpcseg.so")
 
 

@@ -364,6 +364,31 @@ static int ccl_full(KeyFn keyfn, int32_t *labels, int32_t *counts, int B, int H,
     return ccl_compact(ws.parent, ws.blockcount, ws.nblk, labels, counts, PredAll(), true, B, H, W, s);
 }
 
+int ccl_equal_u8_roots_and_ranks(const uint8_t *in, int *codes, int *counts, int **parent, int **blockoff, int *nblk, int B, int H,
+                                 int W, void *workspace, size_t workspace_bytes, hipStream_t s)
+{
+    static_assert(SCAN_PIX == 1024, "region_reduce_col_kernel<.., true> decodes with blocks of 1024 pixels");
+    Carver cv(workspace, workspace_bytes);
+    CclWs ws = ccl_carve(cv, B, H, W);
+    if (!cv.ok()) {
+        set_error("label_regions: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    int rc = ccl_roots<KeyEqU8, true>(KeyEqU8{in, W, (int64_t)H * W}, ws.parent, B, H, W, s);
+    if (rc) return rc;
+    // roots are exact after the border pass (parent[i] == i): count and rank them without flattening anything
+    const int64_t n = (int64_t)H * W;
+    PCSEG_LAUNCH((ccl_flatten_count_kernel<PredAll>), dim3(ws.nblk, B), dim3(256), 0, s, ws.parent, codes, ws.blockcount, PredAll(), n,
+                 ws.nblk, false);
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, ws.blockcount, counts, ws.nblk);
+    PCSEG_CHECK_LAUNCH();
+    *parent = ws.parent;
+    *blockoff = ws.blockcount;
+    *nblk = ws.nblk;
+    return PCSEG_OK;
+}
+
 // ---- roots(+1) image -> parent(-1 bg) conversion for pcseg_compact_labels
 __global__ void __launch_bounds__(256) roots_to_parent_kernel(const int *__restrict__ roots, int *__restrict__ parent, int64_t total)
 {
@@ -418,8 +443,10 @@ __global__ void __launch_bounds__(256) set_bits4_kernel(const uint8_t *__restric
 
 // out = dilate(in, disk(radius)): for every row offset dy the columns within half(dy) = floor(sqrt(r^2 - dy^2)) are
 // OR-ed, then shifted by dy rows across the 32-row words (skimage disk: x^2 + y^2 <= r^2; outside the image = 0)
+// run_parent != nullptr: every vertical run of set bits of the result (a run never leaves its 32-row word) becomes a
+// union-find node named by its top pixel; the node is initialised here, bitrun_link_kernel adds the links.
 __global__ void __launch_bounds__(256) dilate_bits_kernel(const unsigned *__restrict__ in, unsigned *__restrict__ out,
-                                                           int radius, int H, int W, int nch)
+                                                           int radius, int H, int W, int nch, int *__restrict__ run_parent)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int ch = blockIdx.y, b = blockIdx.z;
@@ -448,6 +475,73 @@ __global__ void __launch_bounds__(256) dilate_bits_kernel(const unsigned *__rest
     const int rows = min(32, H - ch * 32);
     if (rows < 32) acc &= (1u << rows) - 1u;
     out[((int64_t)b * nch + ch) * W + c] = acc;
+    if (run_parent) {
+        unsigned heads = acc & ~(acc << 1);
+        int *par = run_parent + (int64_t)b * H * W;
+        while (heads) {
+            const int j = __ffs(heads) - 1;
+            heads &= heads - 1;
+            const int node = (ch * 32 + j) * W + c;
+            par[node] = node;
+        }
+    }
+}
+
+// ---- components of a 1-bit image from its vertical runs (A6: label(dilated mask), tiff_analysis.py:829) ----------
+// The dilated masks of the merge step are only ever LOOKED UP at a few hundred centroid pixels per frame, so no label
+// image is made: the nodes of the union-find are the vertical runs of set bits (named by their top pixel, a few per
+// cent of the pixel count) and only their entries of the pixel-indexed parent array are ever touched.  One thread
+// per 32-row word: each of its runs is linked (8-connectivity) to the runs of the word in the column to the left that
+// overlap rows [top - 1, bottom + 1], and a run that starts in row 0 of the word to the runs that end in row 31 of
+// the three words above (columns c - 1, c, c + 1).  Every adjacent pair of set pixels is covered by one of these
+// rules seen from the right / lower pixel.
+__device__ __forceinline__ int bitrun_start(unsigned word, int p)  // first row of the run of `word` that contains bit p
+{
+    const unsigned below = ~word & ((1u << p) - 1u);
+    return below ? 32 - __clz(below) : 0;
+}
+
+__global__ void __launch_bounds__(256) bitrun_link_kernel(const unsigned *__restrict__ bits, int *__restrict__ parent, int H, int W,
+                                                           int nch)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    if (c >= W) return;
+    const unsigned *wb = bits + (int64_t)b * nch * W;
+    const unsigned w = wb[(int64_t)ch * W + c];
+    if (w == 0) return;
+    int *par = parent + (int64_t)b * H * W;
+    const int row0 = ch * 32;
+    if (c > 0) {
+        const unsigned wl = wb[(int64_t)ch * W + c - 1];
+        unsigned rest = wl ? w : 0u;
+        while (rest) {
+            const int a = __ffs(rest) - 1;                       // top of this run of w
+            const unsigned from_a = w >> a;
+            const int len = from_a == 0xFFFFFFFFu ? 32 : __ffs(~from_a) - 1;
+            const int e = a + len - 1;                           // bottom
+            rest = e >= 31 ? 0u : rest & ~((2u << e) - 1u);
+            const int lo = max(a - 1, 0), hi = min(e + 1, 31);
+            unsigned m = wl & (hi == 31 ? 0xFFFFFFFFu : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
+            const int node = (row0 + a) * W + c;
+            while (m) {
+                const int p = __ffs(m) - 1;
+                const int st = bitrun_start(wl, p);
+                const unsigned from_p = wl >> p;
+                const int run_len = from_p == 0xFFFFFFFFu ? 32 : __ffs(~from_p) - 1;
+                const int en = p + run_len - 1;
+                m = en >= 31 ? 0u : m & ~((2u << en) - 1u);
+                unite_glb(par, node, (row0 + st) * W + c - 1);
+            }
+        }
+    }
+    if ((w & 1u) && ch > 0) {
+        const int node = row0 * W + c;  // the run that starts in row 0 of this word
+        for (int cc = max(c - 1, 0); cc <= min(c + 1, W - 1); ++cc) {
+            const unsigned wu = wb[(int64_t)(ch - 1) * W + cc];
+            if (wu >> 31) unite_glb(par, node, (row0 - 32 + bitrun_start(wu, 31)) * W + cc);
+        }
+    }
 }
 
 // ---- fill holes ------------------------------------------------------------
@@ -673,9 +767,45 @@ int pcseg_dilate_ccl_roots_u8(const uint8_t *in, uint64_t value_bits, int radius
         PCSEG_LAUNCH(set_bits_kernel, g, dim3(256), 0, s, in, (unsigned long long)value_bits, bits, H, W, nch);
     }
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, dil, radius, H, W, nch);
+    PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, dil, radius, H, W, nch, (int *)nullptr);
     PCSEG_CHECK_LAUNCH();
     return ccl_roots<KeyBits, true>(KeyBits{dil, W, nch}, roots, B, H, W, s);
+}
+
+size_t pcseg_dilate_ccl_runs_workspace_bytes(int B, int H, int W)
+{
+    if (!check_shape(B, H, W)) return 0;
+    int nch = (H + 31) / 32;
+    return align_up(sizeof(unsigned) * (size_t)B * nch * W);
+}
+
+int pcseg_dilate_ccl_runs_u8(const uint8_t *in, uint64_t value_bits, int radius, uint32_t *dilated_bits, int32_t *run_parent,
+                             int B, int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(in && dilated_bits && run_parent && workspace && radius >= 0 && radius <= 15 && check_shape(B, H, W),
+                  "bad arguments (radius <= 15)");
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = (H + 31) / 32;
+    Carver cv(workspace, workspace_bytes);
+    unsigned *bits = cv.take<unsigned>((size_t)B * nch * W);
+    if (!cv.ok()) {
+        set_error("dilate_ccl_runs: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    dim3 g((W + 255) / 256, nch, B);
+    if ((W & 3) == 0 && ((uintptr_t)in & 3) == 0 && ((uintptr_t)bits & 15) == 0) {
+        PCSEG_LAUNCH(set_bits4_kernel, dim3((W / 4 + 255) / 256, g.y, g.z), dim3(256), 0, s, in, (unsigned long long)value_bits, bits, H,
+                     W, nch);
+    } else {
+        PCSEG_LAUNCH(set_bits_kernel, g, dim3(256), 0, s, in, (unsigned long long)value_bits, bits, H, W, nch);
+    }
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, (unsigned *)dilated_bits, radius, H, W, nch,
+                 (int *)run_parent);
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_LAUNCH(bitrun_link_kernel, g, dim3(256), 0, s, (const unsigned *)dilated_bits, (int *)run_parent, H, W, nch);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
 }
 
 int pcseg_compact_labels(const int32_t *roots, int32_t *labels, int32_t *counts, int B, int H, int W, void *workspace,

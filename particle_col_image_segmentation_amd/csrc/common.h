@@ -42,7 +42,7 @@ void set_error(const char *fmt, ...);
 // optional per-kernel timing (pcseg_timing_enable): hipEvents recorded around every launch ON THE LAUNCH STREAM
 struct LaunchTimer {
     hipStream_t stream;
-    int slot;
+    void *stop;  // hipEvent_t recorded by the destructor (nullptr: timing off)
     LaunchTimer(const char *kernel, const char *where, hipStream_t s);  // where = __PRETTY_FUNCTION__ (template arguments)
     ~LaunchTimer();
 };
@@ -137,5 +137,11 @@ __device__ __forceinline__ void unite_glb(int *par, int a, int b)
         a = old;
     }
 }
+
+// ccl.hip, for the fused label + region-table driver in reduce.hip: union-find roots of the equal-valued 8-connected
+// components (unflattened parents in the workspace), raster ranks of the roots as codes at the root pixels of `codes`,
+// counts[b], and the scanned per-block offsets (block = 1024 consecutive pixels)
+int ccl_equal_u8_roots_and_ranks(const uint8_t *in, int *codes, int *counts, int **parent, int **blockoff, int *nblk, int B, int H,
+                                 int W, void *workspace, size_t workspace_bytes, hipStream_t s);
 
 }  // namespace pcseg

@@ -4,6 +4,8 @@
 // median, no MFMA (nothing here is a contraction).
 #include <stdarg.h>
 
+#include <atomic>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -29,29 +31,33 @@ struct TimingSlot {
     hipEvent_t a, b;
 };
 static std::mutex g_tmutex;
-static bool g_timing = false;
-static std::vector<TimingSlot> g_slots;
+static std::atomic<bool> g_timing{false};
+static std::deque<TimingSlot> g_slots;  // a deque: growing it never moves the slots other threads hold handles into
 static size_t g_used = 0;
 
-LaunchTimer::LaunchTimer(const char *n, const char *where, hipStream_t s) : stream(s), slot(-1)
+LaunchTimer::LaunchTimer(const char *n, const char *where, hipStream_t s) : stream(s), stop(nullptr)
 {
-    if (!g_timing) return;
-    std::lock_guard<std::mutex> lk(g_tmutex);
-    if (g_used == g_slots.size()) {
-        TimingSlot t{n, where, nullptr, nullptr};
-        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
-        g_slots.push_back(t);
+    if (!g_timing.load(std::memory_order_relaxed)) return;
+    hipEvent_t start;
+    {
+        std::lock_guard<std::mutex> lk(g_tmutex);
+        if (g_used == g_slots.size()) {
+            TimingSlot t{n, where, nullptr, nullptr};
+            if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
+            g_slots.push_back(t);
+        }
+        TimingSlot &slot = g_slots[g_used++];
+        slot.name = n;
+        slot.where = where;
+        start = slot.a;
+        stop = slot.b;  // the destructor records this handle without looking at the table again
     }
-    slot = (int)g_used++;
-    g_slots[slot].name = n;
-    g_slots[slot].where = where;
-    (void)hipEventRecord(g_slots[slot].a, s);
+    (void)hipEventRecord(start, s);
 }
 
 LaunchTimer::~LaunchTimer()
 {
-    if (slot < 0) return;
-    (void)hipEventRecord(g_slots[slot].b, stream);
+    if (stop) (void)hipEventRecord((hipEvent_t)stop, stream);
 }
 
 // ---------------------------------------------------------------- argmax
@@ -277,31 +283,93 @@ __global__ void keys_to_float_kernel(unsigned *keys, int count)
     if (i < count) keys[i] = __float_as_uint(ordered_f32(keys[i]));
 }
 
+// numpy.histogram(float32 image, 256) as skimage.exposure.histogram calls it (scikit-image 0.18.3 / numpy 1.26.4, pinned
+// by tests/golden/extensions.npz): edges = float32(i * ((hi - lo) / 256) + lo) computed in float64 (last edge = hi), the
+// index trunc(((x - lo) / (hi - lo)) * 256) in float32 arithmetic, 256 -> 255, then one step down / up against the
+// float32 edges.  No contraction into FMAs anywhere: the library rounds after every operation.
+__device__ __forceinline__ float otsu_edge(int i, float lo, float hi)
+{
+    if (i >= 256) return hi;
+    const double step = __ddiv_rn(__dsub_rn((double)hi, (double)lo), 256.0);
+    return (float)__dadd_rn(__dmul_rn((double)i, step), (double)lo);
+}
+
 __global__ void __launch_bounds__(256) otsu_hist_kernel(const float *__restrict__ img, const unsigned *__restrict__ lohi_key,
                                                          unsigned long long *__restrict__ hist, int64_t n)
 {
     __shared__ unsigned h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
+    __shared__ float edges[257];
     const int b = blockIdx.y;
     const float *fr = img + (int64_t)b * n;
-    const double lo = (double)ordered_f32(lohi_key[b * 2]), hi = (double)ordered_f32(lohi_key[b * 2 + 1]);
-    const double span = hi - lo;
-    const double norm = span > 0 ? 256.0 / span : 0.0;
+    const float lo = ordered_f32(lohi_key[b * 2]), hi = ordered_f32(lohi_key[b * 2 + 1]);
+    h[threadIdx.x] = 0;
+    edges[threadIdx.x] = otsu_edge(threadIdx.x, lo, hi);
+    if (threadIdx.x == 0) edges[256] = hi;
+    __syncthreads();
+    const float denom = __fsub_rn(hi, lo);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        double x = (double)fr[i];
+        const float x = fr[i];
         int bin = 0;
-        if (span > 0) {
-            bin = (int)((x - lo) * norm);
-            if (bin >= 256) bin = 255;
-            double e0 = lo + span * ((double)bin / 256.0), e1 = lo + span * ((double)(bin + 1) / 256.0);
-            if (x < e0 && bin > 0) --bin;
-            else if (x >= e1 && bin < 255) ++bin;
+        if (hi > lo) {
+            bin = (int)__fmul_rn(__fdiv_rn(__fsub_rn(x, lo), denom), 256.0f);
+            if (bin == 256) bin = 255;
+            if (x < edges[bin]) --bin;
+            if (x >= edges[bin + 1] && bin != 255) ++bin;
         }
         atomicAdd(&h[bin], 1u);
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hist[b * 256 + threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+// skimage.filters.threshold_otsu on that histogram, one frame per block: bin centres (edge[i] + edge[i + 1]) / 2 in
+// float32, class sums as numpy.cumsum builds them -- sequentially, class 1 from the left, class 2 from the RIGHT, in
+// float64 -- variance[i] = (w1[i] * w2[i + 1]) * (mean1[i] - mean2[i + 1])^2, first maximum, threshold = that bin's
+// centre; a constant frame returns its value.  The two 256-step chains are sequential by definition of the library's
+// rounding, so one lane walks them (3 x 256 steps on 256 numbers: microseconds, off any critical path).
+__global__ void __launch_bounds__(64) otsu_threshold_kernel(const unsigned long long *__restrict__ hist, const unsigned *__restrict__ lohi_key,
+                                                             double *__restrict__ thr)
+{
+    __shared__ double p[256], cs2[256];
+    __shared__ float centers[256];
+    __shared__ long long w2[256];
+    const int b = blockIdx.x;
+    const float lo = ordered_f32(lohi_key[b * 2]), hi = ordered_f32(lohi_key[b * 2 + 1]);
+    const unsigned long long *h = hist + (int64_t)b * 256;
+    for (int i = threadIdx.x; i < 256; i += 64) {
+        centers[i] = __fdiv_rn(__fadd_rn(otsu_edge(i, lo, hi), otsu_edge(i + 1, lo, hi)), 2.0f);
+        p[i] = __dmul_rn((double)(long long)h[i], (double)centers[i]);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (!(hi > lo)) {
+        thr[b] = (double)lo;
+        return;
+    }
+    long long acc = 0;
+    double facc = 0.0;
+    for (int i = 255; i >= 0; --i) {
+        acc += (long long)h[i];
+        w2[i] = acc;
+        facc = __dadd_rn(facc, p[i]);
+        cs2[i] = facc;
+    }
+    acc = 0;
+    facc = 0.0;
+    double best = 0.0;
+    int arg = 0;
+    for (int i = 0; i < 255; ++i) {
+        acc += (long long)h[i];
+        facc = __dadd_rn(facc, p[i]);
+        const double m1 = __ddiv_rn(facc, (double)acc), m2 = __ddiv_rn(cs2[i + 1], (double)w2[i + 1]);
+        const double d = __dsub_rn(m1, m2);
+        const double var = __dmul_rn((double)(acc * w2[i + 1]), __dmul_rn(d, d));
+        if (i == 0 || var > best) {
+            best = var;
+            arg = i;
+        }
+    }
+    thr[b] = (double)centers[arg];
 }
 
 }  // namespace pcseg
@@ -315,7 +383,15 @@ int pcseg_version(void) { return 100; }
 void pcseg_timing_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_tmutex);
-    g_timing = on != 0;
+    if (on) {
+        // the event pool is made here, outside any timed region: launches only take slots
+        while (g_slots.size() < 4096) {
+            TimingSlot t{nullptr, nullptr, nullptr, nullptr};
+            if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) break;
+            g_slots.push_back(t);
+        }
+    }
+    g_timing.store(on != 0);
     g_used = 0;
 }
 
@@ -420,6 +496,28 @@ int pcseg_otsu_hist_f32(const float *img, int64_t *hist, float *lohi, int B, int
     PCSEG_LAUNCH(otsu_hist_kernel, dim3(gx, B), dim3(256), 0, s, img, keys, (unsigned long long *)hist, n);
     PCSEG_CHECK_LAUNCH();
     // keys -> float32 lo/hi in place, after every histogram block has read them (stream order)
+    PCSEG_LAUNCH(keys_to_float_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, s, keys, 2 * B);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+int pcseg_otsu_f32(const float *img, double *threshold, int64_t *hist, float *lohi, int B, int H, int W, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(img && threshold && hist && lohi && check_shape(B, H, W), "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t n = (int64_t)H * W;
+    unsigned *keys = reinterpret_cast<unsigned *>(lohi);
+    PCSEG_CHECK_HIP(hipMemsetAsync(hist, 0, sizeof(int64_t) * 256 * B, s));
+    PCSEG_CHECK_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned) * 2 * B, s));
+    for (int b = 0; b < B; ++b) PCSEG_CHECK_HIP(hipMemsetAsync(keys + 2 * b, 0xFF, sizeof(unsigned), s));
+    unsigned gx = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
+    if (gx > 1024) gx = 1024;
+    PCSEG_LAUNCH(minmax_kernel, dim3(gx, B), dim3(256), 0, s, img, keys, n);
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_LAUNCH(otsu_hist_kernel, dim3(gx, B), dim3(256), 0, s, img, keys, (unsigned long long *)hist, n);
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_LAUNCH(otsu_threshold_kernel, dim3(B), dim3(64), 0, s, (const unsigned long long *)hist, (const unsigned *)keys, threshold);
+    PCSEG_CHECK_LAUNCH();
     PCSEG_LAUNCH(keys_to_float_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, s, keys, 2 * B);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;

@@ -102,7 +102,7 @@ __device__ __forceinline__ void ws_store_tile(const T *s, T *__restrict__ g, int
 // After a tile converged: wave e compares edge e of the tile (0 top, 1 bottom, 2 left, 3 right) with what is still in
 // global memory and marks only the neighbour that shares a CHANGED edge.  Must run BEFORE the tile is stored.
 template <typename T>
-__device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__restrict__ g, uint8_t *dirty_out, int *any_marked,
+__device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__restrict__ g, uint8_t *dirty_out,
                                                       int b, int tx, int ty, int tilesX, int tilesY, int r0, int c0, int H, int W)
 {
     const int e = threadIdx.x >> 6, j = threadIdx.x & 63;
@@ -113,13 +113,10 @@ __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__res
     if (r < H && c < W) ch = s[lr * WS_P + lc] != g[(int64_t)r * W + c];
     if (__any(ch) && j == 0) {
         uint8_t *d = dirty_out + (int64_t)b * tilesX * tilesY;
-        bool marked = true;
         if (e == 0 && ty > 0) d[(ty - 1) * tilesX + tx] = 1;
         else if (e == 1 && ty + 1 < tilesY) d[(ty + 1) * tilesX + tx] = 1;
         else if (e == 2 && tx > 0) d[ty * tilesX + tx - 1] = 1;
         else if (e == 3 && tx + 1 < tilesX) d[ty * tilesX + tx + 1] = 1;
-        else marked = false;
-        if (marked && *any_marked == 0) *any_marked = 1;  // the next round has work
     }
 }
 
@@ -151,8 +148,11 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
         unsigned batch_diff = 0;
 #pragma unroll
         for (int j = 0; j < WS_BATCH; ++j) {
-            const unsigned cur = lv[j].x;
-            nw[j] = min(cur, max(lv[j].y, prev));
+            // value <= L holds for every cell (seeds start at their value, everything else at +inf, and a level never
+            // drops below its cell's value), so min(L, max(value, prev)) is the MEDIAN of the three: one v_med3_u32 on
+            // the serial chain instead of v_max followed by v_min
+            const unsigned cur = lv[j].x, v = lv[j].y;
+            nw[j] = min(max(v, prev), max(min(v, prev), cur));
             batch_diff |= cur ^ nw[j];
             prev = nw[j];
         }
@@ -192,14 +192,12 @@ struct WsTiling {
     int nx, ny;  // tiles per frame in x and y
 };
 
-__global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool FIRST, unsigned *__restrict__ val,
-                                                        unsigned *__restrict__ L, uint8_t *__restrict__ dirty_in,
-                                                        uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed,
-                                                        int *__restrict__ any_marked, int H, int W, WsTiling cur, WsTiling nxt,
-                                                        int max_iter)
+// One tile of one round (block-uniform control flow: every return is taken by all 256 threads).
+__device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, const bool FIRST, unsigned *__restrict__ val,
+                                              unsigned *__restrict__ L, uint8_t *__restrict__ dirty_in,
+                                              uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed, int H, int W,
+                                              const WsTiling &cur, const WsTiling &nxt, int max_iter, int tx, int ty, int b)
 {
-    __shared__ uint2 sLV[WS_N];
-    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
     if (!FIRST) {
         // a visited tile takes its mark down itself: the buffer is all zero again when it becomes the output of the
         // round after next, and no memset has to sit between two rounds
@@ -275,7 +273,6 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
             const int oy = (r0 + qy * (WS_T / 2) + nxt.off) / WS_T, ox = (c0 + qx * (WS_T / 2) + nxt.off) / WS_T;
             if (oy >= 0 && oy < nxt.ny && ox >= 0 && ox < nxt.nx) {
                 dirty_out[((int64_t)b * nxt.ny + oy) * nxt.nx + ox] = 1;
-                if (*any_marked == 0) *any_marked = 1;  // the next round has work (read first: most blocks find it set)
             }
         }
     }
@@ -285,13 +282,56 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
         int r = r0 + lr, c = c0 + lc;
         if (r >= 0 && r < H && c >= 0 && c < W) L[fbase + (int64_t)r * W + c] = sLV[(lr + 1) * WS_P + lc + 1].x;
     }
-    if (changed_any && threadIdx.x == 0 && *any_changed == 0) *any_changed = 1;
 }
 
+__global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool FIRST, unsigned *__restrict__ val,
+                                                        unsigned *__restrict__ L, uint8_t *__restrict__ dirty_in,
+                                                        uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed, int H, int W,
+                                                        WsTiling cur, WsTiling nxt, int max_iter)
+{
+    __shared__ uint2 sLV[WS_N];
+    ws_relax_tile(sLV, in, FIRST, val, L, dirty_in, dirty_out, any_changed, H, W, cur, nxt, max_iter, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The fixed point is driven WITHOUT the host: a fixed number of grid rounds is enqueued (a round whose tiles carry no
+// mark costs a few microseconds: every block reads one byte and leaves), and whatever is still marked after them --
+// a few tiles of a few frames, if anything -- is finished by this kernel: one block per frame walks the frame's marked
+// tiles round by round until a round marks nothing.  Rounds of one frame only depend on that frame's tiles, so the
+// block's own barrier is the only synchronisation (stores and loads of one workgroup go through the same L1).
+__global__ void __launch_bounds__(256) ws_relax_tail_kernel(WsInputs in, unsigned *__restrict__ val, unsigned *__restrict__ L,
+                                                             uint8_t *__restrict__ dirtyA, uint8_t *__restrict__ dirtyB,
+                                                             int *__restrict__ any_changed, int *__restrict__ not_converged, int H,
+                                                             int W, WsTiling t0, WsTiling t1, int first_round, int max_rounds)
+{
+    __shared__ uint2 sLV[WS_N];
+    const int b = blockIdx.x;
+    uint8_t *din = dirtyA, *dout = dirtyB;
+    for (int round = first_round;; ++round) {
+        const WsTiling cur = (round & 1) ? t1 : t0, nxt = (round & 1) ? t0 : t1;
+        const int ntiles = cur.nx * cur.ny;
+        const uint8_t *marks = din + (int64_t)b * ntiles;
+        bool any = false;
+        for (int t = threadIdx.x; t < ntiles; t += 256) any = any || marks[t] != 0;
+        if (!__syncthreads_or(any)) return;
+        if (round - first_round >= max_rounds) {  // cannot happen for a monotone fixed point; never spin for ever
+            if (threadIdx.x == 0) *not_converged = 1;
+            return;
+        }
+        for (int t = 0; t < ntiles; ++t) {
+            ws_relax_tile(sLV, in, false, val, L, din, dout, any_changed, H, W, cur, nxt, 100000, t % cur.nx, t / cur.nx, b);
+            __syncthreads();  // the tile's stores (L, marks) before the next tile loads its halo / the next round scans
+        }
+        uint8_t *tmp = din; din = dout; dout = tmp;
+    }
+}
+
+
 // kernels of the second level are launched over the flagged frames only: grid index -> frame id through a list
+// (the list and its length stay on the device: the grid covers the worst case, blocks past the length get -1 and leave)
 __device__ __forceinline__ int ws_frame(const int *frame_list, int grid_index)
 {
-    return frame_list ? frame_list[grid_index] : grid_index;
+    if (!frame_list) return grid_index;
+    return grid_index < frame_list[-1] ? frame_list[grid_index] : -1;
 }
 
 // stage-2 work is restricted to the 64x64 tiles that hold a pixel of an unresolved component (active == nullptr: all)
@@ -368,6 +408,7 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__
     __shared__ int par[UF_TH * UF_TW];
     const KeyT KINF = ~(KeyT)0;
     const int b = ws_frame(frame_list, blockIdx.z);
+    if (b < 0) return;
     const int r0 = blockIdx.y * UF_TH, c0 = blockIdx.x * UF_TW;
     if (!ws_active(active, b, r0, c0, tilesX, tilesY)) return;  // UF tiles (64x32) nest inside the 64x64 tiles
     const int64_t fbase = (int64_t)b * H * W;
@@ -475,6 +516,7 @@ __global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict
         c = (i / H + 1) * UF_TW;
     }
     const int b = ws_frame(frame_list, blockIdx.y);
+    if (b < 0) return;
     if (!ws_active(active, b, r, c, tilesX, tilesY)) return;
     const bool top = (r % UF_TH) == 0 && r > 0;
     const bool left = (c % UF_TW) == 0 && c > 0;
@@ -529,6 +571,7 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = ws_frame(frame_list, blockIdx.y);
+    if (b < 0) return;
     const int r = (int)(i / W), c = (int)(i % W);
     if (i >= n || !ws_active(active, b, r, c, tilesX, tilesY)) return;
     const int64_t fbase = (int64_t)b * n, g = fbase + i;
@@ -647,6 +690,7 @@ __global__ void __launch_bounds__(256) ws_k2_init_kernel(const int *__restrict__
     const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (r >= H || c >= W) return;
     const int b = ws_frame(frame_list, blockIdx.z);
+    if (b < 0) return;
     if (!ws_active(active, b, r, c, tilesX, tilesY)) return;
     const int64_t i = (int64_t)b * H * W + (int64_t)r * W + c;
     const unsigned l = L[i];
@@ -663,21 +707,26 @@ __global__ void __launch_bounds__(256) ws_k2_init_kernel(const int *__restrict__
     K2[i] = k;
 }
 
-__global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
-                                                           unsigned *__restrict__ K2, const uint8_t *__restrict__ active,
-                                                           uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
-                                                           int *__restrict__ any_marked, int H, int W, int tilesX, int tilesY)
+struct WsK2Lds {
+    unsigned sL[WS_N];
+    unsigned sK[WS_N];
+    uint8_t sLake[WS_N];
+};
+
+// one tile of one second-level round (block-uniform control flow, like ws_relax_tile)
+__device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
+                                                 unsigned *__restrict__ K2, const uint8_t *__restrict__ active,
+                                                 uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out, int H, int W,
+                                                 int tilesX, int tilesY, int tx, int ty, int b)
 {
-    __shared__ unsigned sL[WS_N];
-    __shared__ unsigned sK[WS_N];
-    __shared__ uint8_t sLake[WS_N];
-    const int tx = blockIdx.x, ty = blockIdx.y, b = ws_frame(frame_list, blockIdx.z);
+    unsigned *sL = lds.sL, *sK = lds.sK;
+    uint8_t *sLake = lds.sLake;
     if (!active[((int64_t)b * tilesY + ty) * tilesX + tx]) return;  // K2 is only defined inside the active tiles
     {
         uint8_t *mark = dirty_in + ((int64_t)b * tilesY + ty) * tilesX + tx;
         if (!*mark) return;
         __syncthreads();
-        if (threadIdx.x == 0) *mark = 0;  // see ws_relax_kernel
+        if (threadIdx.x == 0) *mark = 0;  // see ws_relax_tile
     }
     const int r0 = ty * WS_T, c0 = tx * WS_T;
     const int64_t fbase = (int64_t)b * H * W;
@@ -709,9 +758,50 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict_
         changed_any = true;
     }
     if (!changed_any) return;
-    ws_mark_changed_edges(sK, (const unsigned *)K2 + fbase, dirty_out, any_marked, b, tx, ty, tilesX, tilesY, r0, c0, H, W);
+    ws_mark_changed_edges(sK, (const unsigned *)K2 + fbase, dirty_out, b, tx, ty, tilesX, tilesY, r0, c0, H, W);
     __syncthreads();
     ws_store_tile(sK, K2 + fbase, r0, c0, H, W);
+}
+
+__global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
+                                                           unsigned *__restrict__ K2, const uint8_t *__restrict__ active,
+                                                           uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
+                                                           int H, int W, int tilesX, int tilesY)
+{
+    __shared__ WsK2Lds lds;
+    const int b = ws_frame(frame_list, blockIdx.z);
+    if (b < 0) return;
+    ws_k2_relax_tile(lds, val, L, K2, active, dirty_in, dirty_out, H, W, tilesX, tilesY, blockIdx.x, blockIdx.y, b);
+}
+
+// the rest of the second-level fixed point after its grid rounds, one block per flagged frame (see ws_relax_tail_kernel)
+__global__ void __launch_bounds__(256) ws_k2_relax_tail_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val,
+                                                                const unsigned *__restrict__ L, unsigned *__restrict__ K2,
+                                                                const uint8_t *__restrict__ active, uint8_t *__restrict__ dirtyA,
+                                                                uint8_t *__restrict__ dirtyB, int *__restrict__ not_converged, int H, int W,
+                                                                int tilesX, int tilesY, int max_rounds)
+{
+    __shared__ WsK2Lds lds;
+    const int b = ws_frame(frame_list, blockIdx.x);
+    if (b < 0) return;
+    uint8_t *din = dirtyA, *dout = dirtyB;
+    const int ntiles = tilesX * tilesY;
+    for (int round = 0;; ++round) {
+        // (a mark on a tile outside the active set is never taken down -- such tiles are not visited -- and is no work)
+        const uint8_t *marks = din + (int64_t)b * ntiles, *act = active + (int64_t)b * ntiles;
+        bool any = false;
+        for (int t = threadIdx.x; t < ntiles; t += 256) any = any || (marks[t] != 0 && act[t] != 0);
+        if (!__syncthreads_or(any)) return;
+        if (round >= max_rounds) {
+            if (threadIdx.x == 0) *not_converged = 1;
+            return;
+        }
+        for (int t = 0; t < ntiles; ++t) {
+            ws_k2_relax_tile(lds, val, L, K2, active, din, dout, H, W, tilesX, tilesY, t % tilesX, t / tilesX, b);
+            __syncthreads();
+        }
+        uint8_t *tmp = din; din = dout; dout = tmp;
+    }
 }
 
 // K64 = (L << 32) | K2 inside the active tiles; every other pixel of
@@ -724,6 +814,7 @@ __global__ void __launch_bounds__(256) ws_pack_kernel(const int *__restrict__ fr
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = ws_frame(frame_list, blockIdx.y);
+    if (b < 0) return;
     if (i >= n || frame_flags[b] == 0) return;
     const int64_t g = (int64_t)b * n + i;
     if (ws_active(active, b, (int)(i / W), (int)(i % W), tilesX, tilesY)) {
@@ -741,19 +832,20 @@ __global__ void __launch_bounds__(256) ws_activate_frames_kernel(const int *__re
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = ws_frame(frame_list, blockIdx.y);
+    if (b < 0) return;
     if (i >= n || frame_flags[b] == 0) return;
     active[((int64_t)b * tilesY + (int)(i / W) / WS_T) * tilesX + (int)(i % W) / WS_T] = 1;
     out[(int64_t)b * n + i] = mask[(int64_t)b * n + i] ? markers[(int64_t)b * n + i] : 0;
 }
 
-// flagged frames, in order, as a device-side list: the host only needs their number
-__global__ void ws_list_flagged_kernel(const int *__restrict__ flags, int B, int *__restrict__ frame_list, int *__restrict__ count)
+// flagged frames, in order, as a device-side list; its length sits in front of it (frame_list[-1], see ws_frame)
+__global__ void ws_list_flagged_kernel(const int *__restrict__ flags, int B, int *__restrict__ frame_list)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int n = 0;
     for (int b = 0; b < B; ++b)
         if (flags[b]) frame_list[n++] = b;
-    *count = n;
+    frame_list[-1] = n;
 }
 
 // the call's tile counters (WS_CNT0 ..) go into a per-device running total, read by pcseg_watershed_counters
@@ -998,25 +1090,6 @@ __global__ void __launch_bounds__(256) ws_exact_kernel(const unsigned *__restric
 
 using namespace pcseg;
 
-// two pinned host ints + two events per host thread: verdicts of the fixed-point windows (see fixed_point below)
-struct PollSlots {
-    int *host = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-};
-static PollSlots *poll_slots()
-{
-    static thread_local PollSlots per_device[64];  // events belong to the device that was current when they were made
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    PollSlots &slots = per_device[dev];
-    if (!slots.host) {
-        if (hipHostMalloc((void **)&slots.host, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
-        for (int i = 0; i < 2; ++i)
-            if (hipEventCreateWithFlags(&slots.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-    }
-    return &slots;
-}
-
 // Round 0 stops every tile after this many sweeps per direction: the round after it visits every tile anyway (with the
 // other tiling), so squeezing the last changes out of isolated tiles is wasted work; a tile cut short marks all four
 // corner tiles.  Measured on the benchmark batch: 16 -> 4.6 % less relaxation time than no limit, 8 -> 1 %, 6 -> none.
@@ -1066,9 +1139,13 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
     if (!check_shape(B, H, W)) return 0;
     size_t n = (size_t)B * H * W;
     int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
-    return 3 * align_up(n * 4) + 3 * align_up(n) + 2 * align_up((size_t)B * (tilesX + 1) * (tilesY + 1)) + align_up((size_t)B * tilesX * tilesY) + align_up(sizeof(int) * WS_CHANGED_INTS) + 3 * align_up(sizeof(int) * B) +
+    return 3 * align_up(n * 4) + 3 * align_up(n) + 2 * align_up((size_t)B * (tilesX + 1) * (tilesY + 1)) + align_up((size_t)B * tilesX * tilesY) + align_up(sizeof(int) * WS_CHANGED_INTS) + 2 * align_up(sizeof(int) * B) + align_up(sizeof(int) * ((size_t)B + 1)) +
            align_up(n * 8) + align_up(n * 4);
 }
+
+// grid rounds enqueued before the per-frame tail kernels take over (see ws_relax_tail_kernel): the benchmark batch needs
+// 10 relaxation rounds; a round without marks costs a few microseconds
+constexpr int WS_GRID_ROUNDS = 12, WS_K2_GRID_ROUNDS = 6;
 
 int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *markers, const uint8_t *mask, int32_t *out,
                          int32_t *tie_flags, int B, int H, int W, int mode, void *workspace, size_t workspace_bytes,
@@ -1090,10 +1167,10 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     uint8_t *dirtyA = cv.take<uint8_t>(ntiles_max);
     uint8_t *dirtyB = cv.take<uint8_t>(ntiles_max);
     uint8_t *active_tiles = cv.take<uint8_t>(ntiles);
-    int *changed = cv.take<int>(WS_CHANGED_INTS);  // [0] any change, [2]/[3] marks, [WS_CNT0 + 32 i] tile counters
+    int *changed = cv.take<int>(WS_CHANGED_INTS);  // [6] "a tail kernel gave up", [WS_CNT0 + 32 i] tile counters
     int *flags = cv.take<int>(B);
     int *flags2 = cv.take<int>(B);
-    int *frame_list = cv.take<int>(B);
+    int *frame_list = cv.take<int>(B + 1) + 1;  // frame_list[-1] = number of flagged frames (stays on the device)
     unsigned long long *heap_key = cv.take<unsigned long long>(n);  // doubles as K64 of the second-level pass
     unsigned *heap_idx = cv.take<unsigned>(n);                      // doubles as K2
     int *uf_parent = cv.take<int>(n);
@@ -1104,47 +1181,10 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         set_error("watershed: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
     }
-    const dim3 tgrid(tilesX, tilesY, B);
     const dim3 pgrid((W + 63) / 64, (H + 3) / 4, B);
-    // Host-driven fixed point.  `launch_round(round, din, dout, any_marked)` enqueues one round that visits the tiles
-    // marked in `din` (each takes its own mark down), marks the next round's tiles in `dout` and raises *any_marked if
-    // it marked any.  The first window has `first_window` rounds, later ones two; a window's verdict (did its last
-    // round mark anything?) travels to pinned host memory behind an event, and the NEXT window is already enqueued
-    // when the host looks at it: if the verdict is "nothing marked", that speculative window finds no marks and its
-    // blocks leave at once, otherwise the GPU never waited for the host.
-    PollSlots *poll = poll_slots();
-    if (!poll) {
-        set_error("watershed: cannot allocate pinned poll slots");
-        return PCSEG_ERR_HIP;
-    }
-    auto fixed_point = [&](int first_window, int max_rounds, auto &&launch_round) -> int {
-        uint8_t *din = dirtyA, *dout = dirtyB;
-        int round = 0;
-        auto window = [&](int rounds, int slot) -> int {
-            int *flag = changed + (slot ? 5 : 2);
-            PCSEG_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
-            for (int k = 0; k < rounds; ++k, ++round) {
-                launch_round(round, din, dout, k == rounds - 1 ? flag : changed + 3);
-                PCSEG_CHECK_LAUNCH();
-                uint8_t *t = din; din = dout; dout = t;
-            }
-            PCSEG_CHECK_HIP(hipMemcpyAsync(poll->host + slot, flag, sizeof(int), hipMemcpyDeviceToHost, s));
-            PCSEG_CHECK_HIP(hipEventRecord(poll->ev[slot], s));
-            return PCSEG_OK;
-        };
-        int rc = window(first_window, 0);
-        if (rc) return rc;
-        for (int cur = 0;; cur ^= 1) {
-            rc = window(2, cur ^ 1);  // speculative
-            if (rc) return rc;
-            PCSEG_CHECK_HIP(hipEventSynchronize(poll->ev[cur]));
-            if (!poll->host[cur]) return PCSEG_OK;
-            if (round > max_rounds) {
-                set_error("watershed: fixed point did not converge");
-                return PCSEG_ERR_HIP;
-            }
-        }
-    };
+    // No host round trip anywhere below: fixed points run a fixed number of grid rounds and finish in a per-frame tail
+    // kernel, the frames that need the second level are listed (and counted) on the device and the second-level
+    // kernels cover the worst-case grid, from which the blocks of unlisted frames leave at once.
     const int max_rounds = (tilesX * tilesY + 64) * 64;
     PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int) * WS_CHANGED_INTS, s));
     long long relax_launches = 0;
@@ -1156,108 +1196,113 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         PCSEG_CHECK_LAUNCH();
     } else {
         const WsInputs inputs{img, frame_stride, markers, mask, out};
-        // minimax relaxation: host-driven rounds over alternating tilings, polled every 4 rounds
+        // minimax relaxation over alternating tilings
         const WsTiling tilings[2] = {{0, tilesX, tilesY}, {WS_T / 2, (W + WS_T / 2 + WS_T - 1) / WS_T, (H + WS_T / 2 + WS_T - 1) / WS_T}};
         // both mark buffers start empty (round 0 visits every tile regardless)
         PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, ntiles_max, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(dirtyB, 0, ntiles_max, s));
-        int rc = fixed_point(8, max_rounds, [&](int round, uint8_t *din, uint8_t *dout, int *any_marked) {
-            const WsTiling &cur = tilings[round & 1], &nxt = tilings[(round + 1) & 1];
-            PCSEG_LAUNCH(ws_relax_kernel, dim3(cur.nx, cur.ny, B), dim3(256), 0, s, inputs, round == 0, val, L, din, dout, changed,
-                         any_marked, H, W, cur, nxt, round == 0 ? WS_ROUND0_SWEEPS : 100000);
-            ++relax_launches;
-        });
-        if (rc) return rc;
+        {
+            uint8_t *din = dirtyA, *dout = dirtyB;
+            for (int round = 0; round < WS_GRID_ROUNDS; ++round) {
+                const WsTiling &cur = tilings[round & 1], &nxt = tilings[(round + 1) & 1];
+                PCSEG_LAUNCH(ws_relax_kernel, dim3(cur.nx, cur.ny, B), dim3(256), 0, s, inputs, round == 0, val, L, din, dout, changed,
+                             H, W, cur, nxt, round == 0 ? WS_ROUND0_SWEEPS : 100000);
+                PCSEG_CHECK_LAUNCH();
+                ++relax_launches;
+                uint8_t *t = din; din = dout; dout = t;
+            }
+            PCSEG_LAUNCH(ws_relax_tail_kernel, dim3(B), dim3(256), 0, s, inputs, val, L, din, dout, changed, changed + 6, H, W,
+                         tilings[0], tilings[1], WS_GRID_ROUNDS, max_rounds);
+            PCSEG_CHECK_LAUNCH();
+        }
         const dim3 ugrid((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B);
         const dim3 lgrid((unsigned)(((size_t)H * W + 255) / 256), B);
         const int64_t npx = (int64_t)H * W;
+        const int64_t border_px = (int64_t)((H - 1) / UF_TH) * W + (int64_t)((W - 1) / UF_TW) * H;
+        const dim3 bgrid((unsigned)((border_px + 255) / 256), B);
         // label assignment = union-find over "minimum-key neighbour" links.  A component holding two marker ids flags
         // its frame, stays unlabelled and (first level) marks its tiles active for the next level.
-        auto assign_labels = [&](auto *keys, const int *flist, int nframes, const uint8_t *act, int *out_flags,
-                                 bool first_level) -> int {
+        auto assign_labels = [&](auto *keys, const int *flist, const uint8_t *act, int *out_flags, bool first_level) -> int {
             using KeyT = std::remove_const_t<std::remove_pointer_t<decltype(keys)>>;
-            const dim3 ug(ugrid.x, ugrid.y, nframes), lg(lgrid.x, nframes);
-            const int64_t border_px = (int64_t)((H - 1) / UF_TH) * W + (int64_t)((W - 1) / UF_TW) * H;
-            const dim3 bg((unsigned)((border_px + 255) / 256), nframes);
-            PCSEG_LAUNCH(ws_uf_tile_kernel<KeyT>, ug, dim3(256), 0, s, flist, (const KeyT *)keys, (const int *)out, act,
+            PCSEG_LAUNCH(ws_uf_tile_kernel<KeyT>, ugrid, dim3(256), 0, s, flist, (const KeyT *)keys, (const int *)out, act,
                          uf_parent, uf_mask, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
             if (border_px > 0) {
-                PCSEG_LAUNCH(ws_uf_border_kernel, bg, dim3(256), 0, s, flist, (const uint8_t *)uf_mask, act, uf_parent, H, W,
+                PCSEG_LAUNCH(ws_uf_border_kernel, bgrid, dim3(256), 0, s, flist, (const uint8_t *)uf_mask, act, uf_parent, H, W,
                              tilesX, tilesY);
                 PCSEG_CHECK_LAUNCH();
             }
             if (first_level && act == nullptr && flist == nullptr && (W & 3) == 0 && ((uintptr_t)out & 15) == 0) {
-                PCSEG_LAUNCH(ws_uf_label4_kernel, dim3((unsigned)((npx / 4 + 255) / 256), nframes), dim3(256), 0, s,
+                PCSEG_LAUNCH(ws_uf_label4_kernel, dim3((unsigned)((npx / 4 + 255) / 256), B), dim3(256), 0, s,
                              (const int *)uf_parent, out, uf_bad1, out_flags, npx);
                 PCSEG_CHECK_LAUNCH();
             } else if (first_level) {
-                PCSEG_LAUNCH(ws_uf_label_kernel<UF_OPTIMISTIC>, lg, dim3(256), 0, s, flist, (const int *)uf_parent, out, act,
+                PCSEG_LAUNCH(ws_uf_label_kernel<UF_OPTIMISTIC>, lgrid, dim3(256), 0, s, flist, (const int *)uf_parent, out, act,
                              uf_bad1, markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY);
                 PCSEG_CHECK_LAUNCH();
             } else {
-                PCSEG_LAUNCH(ws_uf_label_kernel<UF_DETECT>, lg, dim3(256), 0, s, flist, (const int *)uf_parent, out, act, uf_bad2,
+                PCSEG_LAUNCH(ws_uf_label_kernel<UF_DETECT>, lgrid, dim3(256), 0, s, flist, (const int *)uf_parent, out, act, uf_bad2,
                              markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY);
                 PCSEG_CHECK_LAUNCH();
-                PCSEG_LAUNCH(ws_uf_label_kernel<UF_ASSIGN>, lg, dim3(256), 0, s, flist, (const int *)uf_parent, out, act, uf_bad2,
+                PCSEG_LAUNCH(ws_uf_label_kernel<UF_ASSIGN>, lgrid, dim3(256), 0, s, flist, (const int *)uf_parent, out, act, uf_bad2,
                              markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY);
                 PCSEG_CHECK_LAUNCH();
             }
             return PCSEG_OK;
         };
-        uint8_t *active = dirtyB;  // free between the fixed-point loops: which tiles the second level has to revisit
+        uint8_t *active = dirtyB;  // both mark buffers are empty again after a fixed point: free between the two loops
         PCSEG_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * B, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(flags2, 0, sizeof(int) * B, s));
-        PCSEG_CHECK_HIP(hipMemsetAsync(active, 0, ntiles, s));
+        PCSEG_CHECK_HIP(hipMemsetAsync(active, 0, ntiles_max, s));
+        PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, ntiles_max, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(uf_bad1, 0, n, s));
-        rc = assign_labels((const unsigned *)L, (const int *)nullptr, B, (const uint8_t *)nullptr, flags, true);
+        int rc = assign_labels((const unsigned *)L, (const int *)nullptr, (const uint8_t *)nullptr, flags, true);
         if (rc) return rc;
         if (verify) {
             PCSEG_LAUNCH(ws_check_kernel<unsigned>, pgrid, dim3(256), 0, s, (const unsigned *)L, (const int *)out, markers, mask,
                          (const int *)nullptr, flags, H, W);
             PCSEG_CHECK_LAUNCH();
         }
-        // which frames need the second level (launched over exactly those frames): the list stays on the device, the
-        // host reads how many there are
-        int nfl = 0;
-        PCSEG_LAUNCH(ws_list_flagged_kernel, dim3(1), dim3(64), 0, s, (const int *)flags, B, frame_list, changed + 4);
+        // which frames need the second level: list and length stay on the device
+        PCSEG_LAUNCH(ws_list_flagged_kernel, dim3(1), dim3(64), 0, s, (const int *)flags, B, frame_list);
         PCSEG_CHECK_LAUNCH();
-        PCSEG_CHECK_HIP(hipMemcpyAsync(&nfl, changed + 4, sizeof(int), hipMemcpyDeviceToHost, s));
-        PCSEG_CHECK_HIP(hipStreamSynchronize(s));
-        const int any_flag = nfl > 0;
-        if (any_flag) {
+        {
             unsigned *K2 = heap_idx;
             unsigned long long *K64 = heap_key;
-            const dim3 pg2(pgrid.x, pgrid.y, nfl), lg2(lgrid.x, nfl), tg2(tilesX, tilesY, nfl);
+            const dim3 tgrid(tilesX, tilesY, B);
             // the components that hold two marker ids go back to their seeds; their tiles are the second level's work
-            PCSEG_LAUNCH(ws_uf_label_kernel<UF_REPAIR>, lg2, dim3(256), 0, s, (const int *)frame_list, (const int *)uf_parent, out,
+            PCSEG_LAUNCH(ws_uf_label_kernel<UF_REPAIR>, lgrid, dim3(256), 0, s, (const int *)frame_list, (const int *)uf_parent, out,
                          (const uint8_t *)nullptr, uf_bad1, markers, mask, flags, active, npx, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
             PCSEG_CHECK_HIP(hipMemsetAsync(uf_bad2, 0, n, s));
             if (verify) {
                 // whole flagged frames, so that the explicit per-pixel check of the second level sees valid keys everywhere
-                PCSEG_LAUNCH(ws_activate_frames_kernel, lg2, dim3(256), 0, s, (const int *)frame_list, (const int *)flags, active,
+                PCSEG_LAUNCH(ws_activate_frames_kernel, lgrid, dim3(256), 0, s, (const int *)frame_list, (const int *)flags, active,
                              markers, mask, out, npx, W, tilesX, tilesY);
                 PCSEG_CHECK_LAUNCH();
             }
             // the fixed-point loop below reuses dirtyB: keep the active set in its own buffer
             PCSEG_CHECK_HIP(hipMemcpyAsync(active_tiles, active, ntiles, hipMemcpyDeviceToDevice, s));
-            PCSEG_LAUNCH(ws_k2_init_kernel, pg2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
+            PCSEG_LAUNCH(ws_k2_init_kernel, pgrid, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
                          (const unsigned *)L, markers, mask, (const uint8_t *)active_tiles, K2, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
             // marks of the first round = the active tiles; the other buffer (it held the active set) starts empty
             PCSEG_CHECK_HIP(hipMemcpyAsync(dirtyA, active_tiles, ntiles, hipMemcpyDeviceToDevice, s));
             PCSEG_CHECK_HIP(hipMemsetAsync(dirtyB, 0, ntiles_max, s));
-            rc = fixed_point(4, max_rounds, [&](int, uint8_t *din, uint8_t *dout, int *any_marked) {
-                PCSEG_LAUNCH(ws_k2_relax_kernel, tg2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
-                             (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, any_marked, H, W, tilesX, tilesY);
-            });
-            if (rc) return rc;
-            PCSEG_LAUNCH(ws_pack_kernel, lg2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)L, (const unsigned *)K2,
+            uint8_t *din = dirtyA, *dout = dirtyB;
+            for (int round = 0; round < WS_K2_GRID_ROUNDS; ++round) {
+                PCSEG_LAUNCH(ws_k2_relax_kernel, tgrid, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
+                             (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, H, W, tilesX, tilesY);
+                PCSEG_CHECK_LAUNCH();
+                uint8_t *t = din; din = dout; dout = t;
+            }
+            PCSEG_LAUNCH(ws_k2_relax_tail_kernel, dim3(B), dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
+                         (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, changed + 6, H, W, tilesX, tilesY, max_rounds);
+            PCSEG_CHECK_LAUNCH();
+            PCSEG_LAUNCH(ws_pack_kernel, lgrid, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)L, (const unsigned *)K2,
                          (const int *)flags, (const uint8_t *)active_tiles, K64, npx, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            rc = assign_labels((const unsigned long long *)K64, (const int *)frame_list, nfl, (const uint8_t *)active_tiles,
-                               flags2, false);
+            rc = assign_labels((const unsigned long long *)K64, (const int *)frame_list, (const uint8_t *)active_tiles, flags2, false);
             if (rc) return rc;
             if (verify) {
                 PCSEG_LAUNCH(ws_check_kernel<unsigned long long>, pgrid, dim3(256), 0, s, (const unsigned long long *)K64,

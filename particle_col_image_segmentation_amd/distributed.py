@@ -41,10 +41,14 @@ def all_gather_table(table, group=None, sort_cols=(0, 1)):
     return out
 
 
+TABLE_KEYS = ("cells", "rois", "frames", "groups", "distances")
+
+
 def gather_tables(tables, device=None, group=None):
-    """all-gather every table of FramePipeline.tables() (numpy in, numpy out)."""
+    """all-gather every table of FramePipeline.tables() (numpy in, numpy out).  Every rank must pass the same set of
+    2-D tables with the same column counts -- also a rank without a single row (``(0, ncols)`` arrays)."""
     out = dict(tables)
-    for name in [k for k, v in tables.items() if isinstance(v, np.ndarray) and v.ndim == 2]:
+    for name in [k for k in TABLE_KEYS if isinstance(tables.get(k), np.ndarray)]:
         t = torch.from_numpy(np.ascontiguousarray(tables[name], dtype=np.float64))
         if device is not None:
             t = t.to(device)
@@ -53,22 +57,35 @@ def gather_tables(tables, device=None, group=None):
     return out
 
 
-def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None):
+def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, planes=5, **table_kwargs):
     """BASELINE configs 3 / 5: frames ``rank, rank + world, ...`` of a dataset go through ``pipe`` in batches of
     ``batch`` and the per-ROI tables of all ranks are gathered once at the end.  ``make_batch(frame_ids)`` returns the
-    ``(len(frame_ids), C, H, W)`` float32 CUDA stack of those frames (e.g. ``synth.gen_batch_torch`` per seed, or
-    frames written by ``split_zstack.process_tif``)."""
+    ``(len(frame_ids), planes, H, W)`` float32 CUDA stack of those frames (e.g. ``synth.gen_batch_torch`` per seed, or
+    frames written by ``split_zstack.process_tif``).
+
+    Batch k's tables are taken only after batch k + 1 has been handed to the pipeline, so the table assembly and its
+    download run under the next batch's kernels.  A rank that owns no frame (``n_frames < world``) contributes empty
+    tables of the pipeline's schema (``pipe.table_columns``), so that every rank enters the same collectives with the
+    same column counts."""
     rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     mine = shard_frames(n_frames, rank, world)
     parts = []
+    pending = None
     for i in range(0, len(mine), batch):
         ids = mine[i:i + batch]
         res = pipe.run(make_batch(ids))
-        parts.append(pipe.tables(res, frame_ids=ids))
-    if parts:
-        merged = {k: (np.concatenate([p[k] for p in parts]) if isinstance(parts[0][k], np.ndarray) else parts[0][k])
-                  for k in parts[0]}
-    else:
-        merged = {"cells": np.zeros((0, 1)), "rois": np.zeros((0, 1)), "frames": np.zeros((0, 1)), "groups": np.zeros((0, 11))}
+        if pending is not None:
+            parts.append(pipe.tables(pending[0], frame_ids=pending[1], **table_kwargs))
+        pending = (res, ids)
+    if pending is not None:
+        parts.append(pipe.tables(pending[0], frame_ids=pending[1], **table_kwargs))
+    columns = pipe.table_columns(planes, **({"ratios": table_kwargs["ratios"]} if "ratios" in table_kwargs else {}))
+    merged = {}
+    for k in TABLE_KEYS:
+        rows = [p[k] for p in parts if k in p]
+        merged[k] = np.concatenate(rows) if rows else np.zeros((0, len(columns[k])), np.float64)
+        if merged[k].shape[1] != len(columns[k]):
+            raise ValueError("table %r has %d columns, the schema says %d" % (k, merged[k].shape[1], len(columns[k])))
+        merged[k + "_columns"] = columns[k]
     return gather_tables(merged, device=device, group=group)

@@ -109,20 +109,22 @@ def region_reduce(labels, counts=None, cls=None, planes=None, cap=None, sum_clas
         if counts is None:
             raise ValueError("cap or counts is required")
         cap = max(1, int(counts.max().item()))
-    stats = torch.zeros((B, cap, 8), dtype=torch.int64, device=dev)
+    # no zero fill: the library initialises the rows it fills (all of them, or the first counts[b] of frame b); rows
+    # beyond counts[b] are never read by anything that takes `counts`
+    stats = torch.empty((B, cap, 8), dtype=torch.int64, device=dev)
     cls_out = None
     sums = None
     C = 0
     if cls is not None:
         cls = _req(cls, torch.uint8, 3)
-        cls_out = torch.zeros((B, cap), dtype=torch.uint8, device=dev)
+        cls_out = torch.empty((B, cap), dtype=torch.uint8, device=dev)
     if planes is not None:
         planes = _req(planes, torch.float32, 4)
         C = planes.shape[1]
-        sums = torch.zeros((B, cap, C), dtype=torch.float64, device=dev)
+        sums = torch.empty((B, cap, C), dtype=torch.float64, device=dev)
     if counts is not None:
         counts = _req(counts, torch.int32, 1)
-    overflow = torch.zeros((B,), dtype=torch.int32, device=dev)
+    overflow = torch.empty((B,), dtype=torch.int32, device=dev)
     lib = _lib.load()
     if sum_classes and (cls is None or planes is None):
         raise ValueError("sum_classes needs cls and planes")
@@ -130,6 +132,35 @@ def region_reduce(labels, counts=None, cls=None, planes=None, cap=None, sum_clas
                                            cap, _ptr(stats), _ptr(cls_out), _ptr(sums), _ptr(overflow), _stream()),
                "region_reduce")
     return stats, cls_out, sums, overflow
+
+
+def label_regions(z, planes=None, cap=None, sum_classes=0):
+    """label(z) and its region table in one pass (tiff_analysis.py:743, 746-773): what label_equal8 + region_reduce(labels,
+    counts, cls=z, ...) return -- (labels, counts, stats, cls_out, sums, overflow) -- with the label image written once
+    by the kernel that accumulates the table."""
+    z = _req(z, torch.uint8, 3)
+    B, H, W = z.shape
+    dev = z.device
+    if cap is None:
+        cap = max(1024, (H * W) // 64)
+    labels = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    stats = torch.empty((B, cap, 8), dtype=torch.int64, device=dev)   # rows < counts[b] are initialised by the library
+    cls_out = torch.empty((B, cap), dtype=torch.uint8, device=dev)
+    sums = None
+    C = 0
+    if planes is not None:
+        planes = _req(planes, torch.float32, 4)
+        C = planes.shape[1]
+        sums = torch.empty((B, cap, C), dtype=torch.float64, device=dev)
+    overflow = torch.empty((B,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    nbytes = lib.pcseg_label_regions_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, dev)
+    _lib.check(lib.pcseg_label_regions_u8(_ptr(z), ctypes.c_uint64(int(sum_classes)), _ptr(planes), C, _ptr(labels), _ptr(counts),
+                                          B, H, W, cap, _ptr(stats), _ptr(cls_out), _ptr(sums), _ptr(overflow), _ptr(ws), nbytes,
+                                          _stream()), "label_regions")
+    return labels, counts, stats, cls_out, sums, overflow
 
 
 def threshold_lt(img, threshold):
@@ -266,6 +297,43 @@ def dilated_roots(x, value_bits, radius):
     return roots
 
 
+def dilated_runs(x, value_bits, radius, run_parent=None):
+    """components of binary_dilation(((value_bits >> x) & 1), disk(radius)) WITHOUT a label image (A6): the dilated
+    mask as 32-row column words int32 (B, ceil(H/32), W) and a union-find over its vertical runs (int32 (B,H,W) scratch
+    of which only the run-head entries are written; pass ``run_parent`` to reuse one).  For merge_groups_runs."""
+    x = _req(x, torch.uint8, 3)
+    B, H, W = x.shape
+    lib = _lib.load()
+    bits = torch.empty((B, (H + 31) // 32, W), dtype=torch.int32, device=x.device)
+    if run_parent is None:
+        run_parent = torch.empty((B, H, W), dtype=torch.int32, device=x.device)
+    nbytes = lib.pcseg_dilate_ccl_runs_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, x.device)
+    _lib.check(lib.pcseg_dilate_ccl_runs_u8(_ptr(x), ctypes.c_uint64(int(value_bits)), int(radius), _ptr(bits), _ptr(run_parent),
+                                            B, H, W, _ptr(ws), nbytes, _stream()), "dilated_runs")
+    return bits, run_parent
+
+
+def merge_groups_runs(bits, run_parent, stats, region_list, n_list):
+    """get_merged_regions grouping (tiff_analysis.py:843-878) on the run components of dilated_runs()."""
+    bits = _req(bits, torch.int32, 3)
+    run_parent = _req(run_parent, torch.int32, 3)
+    stats = _req(stats, torch.int64, 3)
+    region_list = _req(region_list, torch.int32, 2)
+    n_list = _req(n_list, torch.int32, 1)
+    B, H, W = run_parent.shape
+    cap = stats.shape[1]
+    list_cap = region_list.shape[1]
+    lib = _lib.load()
+    group_of = torch.zeros((B, list_cap), dtype=torch.int32, device=stats.device)
+    n_groups = torch.zeros((B,), dtype=torch.int32, device=stats.device)
+    nbytes = lib.pcseg_merge_groups_workspace_bytes(B, list_cap)
+    ws = _ws(nbytes, stats.device)
+    _lib.check(lib.pcseg_merge_groups_runs(_ptr(bits), _ptr(run_parent), _ptr(stats), _ptr(region_list), _ptr(n_list), _ptr(group_of),
+                                           _ptr(n_groups), B, H, W, cap, list_cap, _ptr(ws), nbytes, _stream()), "merge_groups_runs")
+    return group_of, n_groups
+
+
 def merge_groups(dilated_labels, stats, region_list, n_list, roots=False):
     """get_merged_regions grouping (tiff_analysis.py:843-878): group id per list entry, 0 = dropped.
     roots=True: `dilated_labels` is the parent image of dilated_roots()."""
@@ -359,6 +427,65 @@ def classify_regions(stats, cls_out, counts, tables):
     return out
 
 
+def build_tables(res, groups, frame_ids, C, ratios):
+    """csrc/tables.hip: dense row tables of one batch (see FramePipeline.tables_device)."""
+    lib = _lib.load()
+    B, cap = res["stats"].shape[0], res["stats"].shape[1]
+    dev = res["stats"].device
+    if len(ratios) > 8 or any(len(den) > 4 for _, _, den in ratios):
+        raise ValueError("at most 8 ratios of at most 4 denominator planes")
+    ti = _lib.TableInputs()
+    ti.B, ti.cap, ti.C, ti.n_ratios = B, cap, C, len(ratios)
+    keep = []  # tensors referenced by raw pointers until the kernels are enqueued
+
+    def ptr(t, dtype, shape):
+        t = _req(t, dtype, len(shape))
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("table input of shape %s, expected %s" % (tuple(t.shape), tuple(shape)))
+        keep.append(t)
+        return t.data_ptr()
+
+    ti.frame_ids = ptr(frame_ids, torch.int64, (B,))
+    ti.counts = ptr(res["counts"], torch.int32, (B,))
+    ti.stats = ptr(res["stats"], torch.int64, (B, cap, 8))
+    ti.cls_out = ptr(res["cls_out"], torch.uint8, (B, cap))
+    ti.cc_sums = ptr(res["cc_sums"], torch.float64, (B, cap, C))
+    ti.kind = ptr(res["kind"], torch.uint8, (B, cap))
+    ti.slot_of = ptr(res["slot_of"], torch.uint8, (B, cap))
+    ti.cells = ptr(res["cells"], torch.int32, (B, cap))
+    ti.particle_area = ptr(res["particle_area"], torch.int64, (B,))
+    ti.overlap_area = ptr(res["overlap_area"], torch.int64, (B,))
+    ti.type_stats = ptr(res["type_stats"], torch.int64, (B, 4, 4))
+    ti.tie_flags = ptr(res["tie_flags"], torch.int32, (B,))
+    ti.region_list = ptr(res["region_list"], torch.int32, (B, 5, cap))
+    ti.n_list = ptr(res["n_list"], torch.int32, (B, 5))
+    for s, g in groups.items():
+        ti.group_of[s] = ptr(g["group_of"], torch.int32, (B, cap))
+        ti.n_groups[s] = ptr(g["n_groups"], torch.int32, (B,))
+        ti.group_stats[s] = ptr(g["group_stats"], torch.int64, (B, cap, 8))
+    ti.n_markers = ptr(res["n_markers"], torch.int32, (B,))
+    ti.ws_stats = ptr(res["ws_stats"], torch.int64, (B, cap, 8))
+    ti.ws_sums = ptr(res["ws_sums"], torch.float64, (B, cap, C))
+    for k, (_, num, den) in enumerate(ratios):
+        ti.ratio_num[k] = int(num)
+        for j in range(4):
+            ti.ratio_den[k][j] = int(den[j]) if j < len(den) else -1
+    nbytes = lib.pcseg_table_workspace_bytes(B, cap)
+    ws = _ws(nbytes, dev)
+    totals = torch.empty((3,), dtype=torch.int64, device=dev)
+    _lib.check(lib.pcseg_table_layout(ctypes.byref(ti), _ptr(totals), _ptr(ws), nbytes, _stream()), "table_layout")
+    n_roi, n_cell, n_group = (int(v) for v in totals.cpu())  # the one host read: sizes of the outputs
+    nr = len(ratios)
+    # (one spare row each: an empty table still needs a non-null pointer for the library's argument check)
+    rois = torch.empty((n_roi + 1, 5 + C + nr), dtype=torch.float64, device=dev)
+    cells = torch.empty((n_cell + 1, 14 + C + nr), dtype=torch.float64, device=dev)
+    grp = torch.empty((n_group + 1, 11), dtype=torch.float64, device=dev)
+    frames = torch.empty((B, 17), dtype=torch.int64, device=dev)
+    _lib.check(lib.pcseg_table_write(ctypes.byref(ti), _ptr(rois), _ptr(cells), _ptr(grp), _ptr(frames), _ptr(ws), nbytes,
+                                     _stream()), "table_write")
+    return {"rois": rois[:n_roi], "cells": cells[:n_cell], "groups": grp[:n_group], "frames": frames, "frame_ids": frame_ids}
+
+
 def remove_overlapping(dapi, other, threshold):
     """combine_cell_positions_and_clusters (tiff_analysis.py:252-287)."""
     dapi = _req(dapi, torch.uint8, 3)
@@ -408,27 +535,15 @@ def nearest_dist(a, b):
     return out
 
 
-def threshold_otsu(img):
-    """Otsu threshold per frame from the device histogram (north_star extension X1, no reference call site): bin
-    centres over [min, max], between-class variance maximised over the split index (host epilogue on 256 numbers)."""
-    import numpy as np
-    hist, lohi = otsu_hist(img)
-    h = hist.cpu().numpy().astype(np.float64)
-    lh = lohi.cpu().numpy().astype(np.float64)
-    out = np.empty(h.shape[0], np.float64)
-    for b in range(h.shape[0]):
-        lo, hi = lh[b]
-        if hi == lo:
-            out[b] = lo
-            continue
-        edges = lo + (hi - lo) * (np.arange(257) / 256.0)
-        centers = (edges[:-1] + edges[1:]) / 2.0
-        w1 = np.cumsum(h[b])[:-1]
-        s1 = np.cumsum(h[b] * centers)[:-1]
-        wt, stt = h[b].sum(), (h[b] * centers).sum()
-        w2 = wt - w1
-        with np.errstate(all="ignore"):
-            var = w1 * w2 * (s1 / w1 - (stt - s1) / w2) ** 2
-        var[(w1 == 0) | (w2 == 0)] = -1.0
-        out[b] = centers[int(np.argmax(var))]
-    return out
+def threshold_otsu(img, return_hist=False):
+    """skimage.filters.threshold_otsu per frame, entirely on the device (north_star extension X1; the library itself
+    is the pin: tests/golden/extensions.npz): float64 (B,) CUDA tensor holding the float32 bin centre the
+    library returns.  ``return_hist``: also the (B,256) histogram and the (B,2) [min, max] it was taken from."""
+    img = _req(img, torch.float32, 3)
+    B, H, W = img.shape
+    lib = _lib.load()
+    thr = torch.empty((B,), dtype=torch.float64, device=img.device)
+    hist = torch.empty((B, 256), dtype=torch.int64, device=img.device)
+    lohi = torch.empty((B, 2), dtype=torch.float32, device=img.device)
+    _lib.check(lib.pcseg_otsu_f32(_ptr(img), _ptr(thr), _ptr(hist), _ptr(lohi), B, H, W, _stream()), "otsu")
+    return (thr, hist, lohi) if return_hist else thr

@@ -36,14 +36,24 @@ class BatchResult(dict):
     _pending = None
 
     def synchronize(self):
-        pending, self._pending = self._pending, None
+        pending = self._pending
         if pending is None:
             return self
-        if hasattr(pending, "result"):  # a lane's future: (entries, closing events); re-raises what the lane raised
-            entries, pending = pending.result()
+        events = pending
+        if hasattr(pending, "result"):  # a lane's future: (entries, closing events)
+            # a lane that raised keeps raising here on every read: _pending is only cleared after a clean hand-over
+            entries, events = pending.result()
             dict.update(self, entries)
-        for ev in pending:
+        for ev in events:
             ev.synchronize()
+        # the tensors were allocated on the lane's streams: tell the caching allocator that the caller's stream uses
+        # them too, so that dropping this result cannot hand their blocks to the lane's next batch while a kernel the
+        # caller enqueued is still reading them
+        cur = torch.cuda.current_stream()
+        for t in _tensors(dict.values(self)):
+            if t.is_cuda:
+                t.record_stream(cur)
+        self._pending = None
         return self
 
     def __getitem__(self, key):
@@ -94,6 +104,14 @@ class BatchResult(dict):
             # tiff_analysis.py:776-781: clusters of a type without any single cell -> int(NaN)
             raise ValueError("cannot convert float NaN to integer")
         return self
+
+
+def _tensors(values):
+    for v in values:
+        if isinstance(v, torch.Tensor):
+            yield v
+        elif isinstance(v, dict):
+            yield from _tensors(v.values())
 
 
 _LANES = {}  # (device index, lanes) -> (executors, stream pairs): shared by every pipeline of the process
@@ -182,12 +200,11 @@ class FramePipeline:
         z = ops.median5(cls)
         res["denoised"] = z
         # ---- label + region table (+ isotope sums of the class components) (A2, A3, M1)
-        labels, counts = ops.label_equal8(z)
         # isotope sums are only ever reported for cell / cluster regions: the planes are read under those classes only
         cell_bits = 0
         for v in tb.cell_values:
             cell_bits |= 1 << int(v)
-        stats, cls_out, cc_sums, overflow = ops.region_reduce(labels, counts, cls=z, planes=stack, cap=cap, sum_classes=cell_bits)
+        labels, counts, stats, cls_out, cc_sums, overflow = ops.label_regions(z, planes=stack, cap=cap, sum_classes=cell_bits)
         res.update(labels=labels, counts=counts, stats=stats, cls_out=cls_out, cc_sums=cc_sums, overflow=overflow)
         # ---- classification, cluster cell counts, region lists (A3 tail, A4)
         res.update(ops.classify_regions(stats, cls_out, counts, tb))
@@ -204,11 +221,12 @@ class FramePipeline:
                     bits = bits_all
                 if bits == 0:
                     continue
-                # dilated components as union-find roots on the 1-bit image: grouping only needs "same component"
-                dl = ops.dilated_roots(z, bits, ta.CELL_CLUSTER_DISTANCE_THRESHOLD // 2)
+                # dilated components as a union-find over the vertical runs of the 1-bit image: grouping only needs "same
+                # component" at the centroid pixels, so no label image is ever written
+                dbits, run_par = ops.dilated_runs(z, bits, ta.CELL_CLUSTER_DISTANCE_THRESHOLD // 2)
                 lst = res["region_list"][:, s].contiguous()
                 nl = res["n_list"][:, s].contiguous()
-                gof, ng = ops.merge_groups(dl, stats, lst, nl, roots=True)
+                gof, ng = ops.merge_groups_runs(dbits, run_par, stats, lst, nl)
                 gst = ops.group_reduce(stats, lst, nl, gof, ng, H, W)
                 groups[s] = {"group_of": gof, "n_groups": ng, "group_stats": gst}
             res["groups"] = groups
@@ -235,109 +253,85 @@ class FramePipeline:
         ws_stats, _, ws_sums, ws_overflow = ops.region_reduce(ws_labels, n_markers, planes=stack, cap=cap)
         res.update(ws_stats=ws_stats, ws_sums=ws_sums, ws_overflow=ws_overflow)
 
-    # ------------------------------------------------------------------ host epilogue
-    def tables(self, res, frame_ids=None, ratios=RATIOS_5, distances=False, raster=19.0, check=True):
-        """Download one batch as numpy tables: ``cells`` (one row per cell / cluster region), ``rois`` (one row per
-        refined ROI), ``frames`` (one row per frame) and ``groups`` (one row per merged group).  ``check=False`` skips
-        ``BatchResult.check`` (a caller that has looked at the flags itself, e.g. to keep the ROI rows of a batch in
-        which the reference would have raised on one frame's cluster statistics)."""
+    # ------------------------------------------------------------------ table output
+    def table_columns(self, C, ratios=RATIOS_5):
+        """Column names of every table of :meth:`tables` (known without any data: ranks that own no frame of a
+        dataset still agree on the schema, see ``distributed.run_sharded``)."""
+        tb = self.tables_
+        rn = [r[0] for r in ratios]
+        return {
+            "cells": ["frame", "label", "class", "kind", "area", "centroid_row", "centroid_col", "min_row", "min_col",
+                      "max_row1", "max_col1", "cells", "group", "group_combined"] + ["S%d" % k for k in range(C)] + rn,
+            "rois": ["frame", "label", "area", "centroid_row", "centroid_col"] + ["S%d" % k for k in range(C)] + rn,
+            "frames": ["frame", "n_labels", "n_rois", "particle_area", "particle_area_recreated", "tie_flag"]
+                      + [c % n for n in tb.slot_names for c in ("%s_present", "%s_count", "%s_density", "%s_area_ratio")],
+            "distances": ["frame", "label", "nearest_other_type_um"],
+            "groups": ["frame", "slot", "group", "area", "centroid_row", "centroid_col", "min_row", "min_col",
+                       "max_row1", "max_col1", "members"],
+        }
+
+    def tables_device(self, res, frame_ids=None, ratios=RATIOS_5, check=True):
+        """The batch as dense row tables, assembled ON THE DEVICE (``csrc/tables.hip``): float64 CUDA tensors ``rois``,
+        ``cells``, ``groups`` and the int64 ``frames`` record (see ``pcseg_table_write`` in include/pcseg.h).  One small
+        device-to-host copy (three row totals) sizes the outputs; nothing else leaves the GPU, so the ROI table can go
+        straight into the all-gather."""
         if check:
             res.check()
         else:
             res.synchronize()
         B, C, H, W = res["shape"]
-        frame_ids = np.arange(B) if frame_ids is None else np.asarray(frame_ids)
+        dev = res["stats"].device
+        if frame_ids is None:
+            fid = torch.arange(B, dtype=torch.int64, device=dev)
+        else:
+            fid = torch.as_tensor(list(frame_ids), dtype=torch.int64).to(dev)
+        groups = (res.get("groups") or {}) if self.merged else {}
+        return ops.build_tables(res, groups, fid, C, ratios)
+
+    def tables(self, res, frame_ids=None, ratios=RATIOS_5, distances=False, raster=19.0, check=True):
+        """Download one batch as numpy tables: ``cells`` (one row per cell / cluster region), ``rois`` (one row per
+        refined ROI), ``frames`` (one row per frame) and ``groups`` (one row per merged group).  The rows are built by
+        :meth:`tables_device`; the host only applies the two ``round(x, 5)`` of get_cell_counts_and_densities
+        (tiff_analysis.py:1018-1038; Python's decimal rounding) to B x n_types numbers.  ``check=False`` skips
+        ``BatchResult.check`` (a caller that has looked at the flags itself, e.g. to keep the ROI rows of a batch in
+        which the reference would have raised on one frame's cluster statistics)."""
+        B, C, H, W = res["shape"]
+        dt = self.tables_device(res, frame_ids, ratios, check)
+        cols = self.table_columns(C, ratios)
         tb = self.tables_
-        h = lambda k: res[k].cpu().numpy()
-        counts, stats, cls_out, cc_sums = h("counts"), h("stats"), h("cls_out"), h("cc_sums")
-        kind, slot_of, cells = h("kind"), h("slot_of"), h("cells")
-        pa, ovl, tstats = h("particle_area"), h("overlap_area"), h("type_stats")
-        n_ws, ws_stats, ws_sums, ties = h("n_markers"), h("ws_stats"), h("ws_sums"), h("tie_flags")
-        group_of = {}
-        if self.merged:
-            for s, g in res["groups"].items():
-                group_of[s] = (g["group_of"].cpu().numpy(), g["n_groups"].cpu().numpy(), g["group_stats"].cpu().numpy(),
-                               res["region_list"][:, s].cpu().numpy(), res["n_list"][:, s].cpu().numpy())
-        nr = len(ratios)
-        cell_rows, roi_rows, frame_rows, group_rows, dist_rows = [], [], [], [], []
+        out = {k: dt[k].cpu().numpy() for k in ("cells", "rois", "groups")}
+        rec = dt["frames"].cpu().numpy()
+        fid = dt["frame_ids"].cpu().numpy()
+        px2 = ta.PX_TO_UM_CONV ** 2
+        frame_rows = []
         for b in range(B):
-            n = int(counts[b])
-            st, sums = stats[b, :n], cc_sums[b, :n]
-            own = np.zeros(n, np.int64)
-            comb = np.zeros(n, np.int64)
-            for s, (gof, ng, gst, lst, nl) in group_of.items():
-                k = int(nl[b])
-                tgt = comb if s == 4 else own
-                tgt[lst[b, :k]] = gof[b, :k]
-                for gi in range(int(ng[b])):
-                    t = gst[b, gi]
-                    group_rows.append([frame_ids[b], s, gi + 1, t[0], t[1] / t[0], t[2] / t[0], t[3], t[4], t[5], t[6], t[7]])
-            sel = np.nonzero(kind[b, :n] > 0)[0]
-            for r in sel:
-                a = float(st[r, 0])
-                cell_rows.append([frame_ids[b], r + 1, cls_out[b, r], kind[b, r], st[r, 0], st[r, 1] / a, st[r, 2] / a,
-                                  st[r, 3], st[r, 4], st[r, 5], st[r, 6], cells[b, r], own[r], comb[r]]
-                                 + list(sums[r]) + _ratios(sums[r], ratios))
-            m = int(n_ws[b])
-            for r in range(m):
-                a = float(ws_stats[b, r, 0])
-                if a == 0:
-                    continue
-                roi_rows.append([frame_ids[b], r + 1, ws_stats[b, r, 0], ws_stats[b, r, 1] / a, ws_stats[b, r, 2] / a]
-                                + list(ws_sums[b, r]) + _ratios(ws_sums[b, r], ratios))
-            row = [frame_ids[b], n, m, pa[b], pa[b] + ovl[b], ties[b]]
-            pa_um = pa[b] / (ta.PX_TO_UM_CONV ** 2)
+            row = [float(fid[b])] + [float(v) for v in rec[b, :5]]
+            pa_um = float(rec[b, 2]) / px2
             for s in range(len(tb.slot_names)):
-                ncell, nclu, sumcell, first = tstats[b, s]
-                present = first != 0x7FFFFFFF
-                clu = (kind[b, :n] == 2) & (slot_of[b, :n] == s)
-                count = int(ncell + cells[b, :n][clu].sum())
-                area = (sumcell + st[clu, 0].sum()) / (ta.PX_TO_UM_CONV ** 2)
-                with np.errstate(all="ignore"):
-                    dens = round(count / pa_um, 5) if present and pa_um else float("nan")
-                    ratio = round(area / pa_um, 5) if present and pa_um else float("nan")
-                row += [int(present), count, dens, ratio]
-            if distances:
-                # .m:260-268 per frame: nearest ROI of the other cell type for the cells / clusters of slots 0 and 1
-                a = [[st[r, 2] / st[r, 0] + 1.0, st[r, 1] / st[r, 0] + 1.0] for r in sel if slot_of[b, r] == 0]
-                c = [[st[r, 2] / st[r, 0] + 1.0, st[r, 1] / st[r, 0] + 1.0] for r in sel if slot_of[b, r] == 1]
-                if a and c:
-                    dev = res["stats"].device
-                    ta_ = torch.tensor(a, dtype=torch.float64, device=dev)
-                    tc_ = torch.tensor(c, dtype=torch.float64, device=dev)
-                    da, dc = ops.nearest_dist(ta_, tc_).cpu().numpy(), ops.nearest_dist(tc_, ta_).cpu().numpy()
-                    ia = [r for r in sel if slot_of[b, r] == 0]
-                    ic = [r for r in sel if slot_of[b, r] == 1]
-                    for r, d in list(zip(ia, da)) + list(zip(ic, dc)):
-                        dist_rows.append([frame_ids[b], r + 1, d / (512.0 / raster)])
+                present, count, area_px = (int(v) for v in rec[b, 5 + 3 * s: 8 + 3 * s])
+                dens = round(count / pa_um, 5) if present and pa_um else float("nan")
+                ratio = round((area_px / px2) / pa_um, 5) if present and pa_um else float("nan")
+                row += [float(present), float(count), dens, ratio]
             frame_rows.append(row)
-        ncols_cell = 14 + C + nr
-        ncols_roi = 5 + C + nr
-        return {
-            "cells": np.array(cell_rows, np.float64).reshape(-1, ncols_cell),
-            "cells_columns": ["frame", "label", "class", "kind", "area", "centroid_row", "centroid_col", "min_row", "min_col",
-                              "max_row1", "max_col1", "cells", "group", "group_combined"]
-                             + ["S%d" % k for k in range(C)] + [r[0] for r in ratios],
-            "rois": np.array(roi_rows, np.float64).reshape(-1, ncols_roi),
-            "rois_columns": ["frame", "label", "area", "centroid_row", "centroid_col"]
-                            + ["S%d" % k for k in range(C)] + [r[0] for r in ratios],
-            "frames": np.array(frame_rows, np.float64).reshape(B, -1),
-            "frames_columns": ["frame", "n_labels", "n_rois", "particle_area", "particle_area_recreated", "tie_flag"]
-                              + [c % n for n in tb.slot_names for c in ("%s_present", "%s_count", "%s_density", "%s_area_ratio")],
-            "distances": np.array(dist_rows, np.float64).reshape(-1, 3),
-            "distances_columns": ["frame", "label", "nearest_other_type_um"],
-            "groups": np.array(group_rows, np.float64).reshape(-1, 11),
-            "groups_columns": ["frame", "slot", "group", "area", "centroid_row", "centroid_col", "min_row", "min_col",
-                               "max_row1", "max_col1", "members"],
-        }
-
-
-def _ratios(s, ratios):
-    out = []
-    for _, num, den in ratios:
-        d = 0.0
-        for k in den:
-            d = d + s[k]
-        with np.errstate(all="ignore"):
-            out.append(float(np.float64(s[num]) / np.float64(d)) if len(s) > max(den + (num,)) else float("nan"))
-    return out
+        out["frames"] = np.array(frame_rows, np.float64).reshape(B, len(cols["frames"]))
+        dist_rows = []
+        if distances:
+            # .m:260-268 per frame: nearest ROI of the other cell type for the cells / clusters of slots 0 and 1
+            cells = out["cells"]
+            slot = tb.slot[cells[:, 2].astype(np.int64)] if len(cells) else np.zeros(0, np.uint8)
+            for f in fid:
+                rows = cells[:, 0] == f
+                pos = {}
+                for s in (0, 1):
+                    sel = cells[rows & (slot == s)]
+                    pos[s] = (sel[:, 1], np.stack([sel[:, 6] + 1.0, sel[:, 5] + 1.0], axis=1))
+                if len(pos[0][0]) and len(pos[1][0]):
+                    ta_ = torch.from_numpy(np.ascontiguousarray(pos[0][1])).to(dt["rois"].device)
+                    tc_ = torch.from_numpy(np.ascontiguousarray(pos[1][1])).to(dt["rois"].device)
+                    da, dc = ops.nearest_dist(ta_, tc_).cpu().numpy(), ops.nearest_dist(tc_, ta_).cpu().numpy()
+                    for lab, d in list(zip(pos[0][0], da)) + list(zip(pos[1][0], dc)):
+                        dist_rows.append([f, lab, d / (512.0 / raster)])
+        out["distances"] = np.array(dist_rows, np.float64).reshape(-1, 3)
+        for k, v in cols.items():
+            out[k + "_columns"] = v
+        return out

@@ -460,6 +460,50 @@ def split_case():
     save("split_zstack", **out)
 
 
+# ---------------------------------------------------------------------------
+# north_star extensions without a reference call site (refine_boundaries.py:22 imports ``filters`` and never calls
+# it): pinned against the libraries SURVEY.md 8a names as their oracle -- skimage.filters.threshold_otsu (X1) and the
+# 3x3 binary erosion / dilation of skimage.morphology / scipy.ndimage (X2).
+# ---------------------------------------------------------------------------
+def ext_cases():
+    from skimage import filters
+    from skimage.morphology import binary_erosion, square
+    rng = np.random.default_rng(4321)
+    out = {}
+    images = []
+    images.append(rng.random((100, 90)).astype(np.float32))                                   # uniform noise
+    images.append(np.concatenate([rng.normal(0.2, 0.05, 4000), rng.normal(0.7, 0.1, 2000)]).astype(np.float32).reshape(60, 100))
+    images.append(np.full((17, 9), 0.37, np.float32))                                         # constant image
+    two = np.where(rng.random((33, 47)) < 0.3, np.float32(0.125), np.float32(0.875)).astype(np.float32)
+    images.append(two)                                                                        # two values
+    # values that sit exactly on / next to the float32 bin edges of a [0, 1] histogram (1024 candidates for 256 bins)
+    edge = (np.arange(1024, dtype=np.float64) / 1024.0).astype(np.float32)
+    adv = np.concatenate([edge, np.nextafter(edge, np.float32(2)), np.nextafter(edge, np.float32(-1)), [np.float32(1.0)]])
+    images.append(np.resize(adv, (64, 49)).astype(np.float32))
+    images.append((rng.random((40, 40)) * 2000.0 - 700.0).astype(np.float32))                 # negative values, wide range
+    images.append(synth.gen_frame(11, 128, 128)[3])                                           # a boundary-probability plane
+    images.append(synth.gen_frame(12, 96, 160, ties=True)[3])                                 # quantised to k/100
+    for i, img in enumerate(images):
+        thr = filters.threshold_otsu(img)
+        out["otsu_%02d_inp" % i] = img
+        out["otsu_%02d_thr" % i] = np.float64(thr)
+        if not np.all(img == img.ravel()[0]):  # (a constant image returns before any histogram is made)
+            from skimage.exposure import histogram as sk_histogram
+            out["otsu_%02d_hist" % i] = sk_histogram(img, 256)[0].astype(np.int64)
+        out["otsu_%02d_thr_is_f32" % i] = np.bool_(np.asarray(thr).dtype == np.float32)
+    masks = [rng.random((50, 70)) < 0.5, rng.random((31, 33)) < 0.8, np.ones((9, 12), bool), np.zeros((7, 5), bool),
+             rng.random((1, 40)) < 0.6, rng.random((40, 1)) < 0.6, rng.random((64, 64)) < 0.2]
+    se = np.ones((3, 3), bool)
+    for i, m in enumerate(masks):
+        out["morph_%02d_inp" % i] = m
+        # scikit-image's own conventions (binary.py): erosion treats the outside as True, dilation as False
+        out["morph_%02d_erode" % i] = binary_erosion(m, square(3))
+        out["morph_%02d_dilate" % i] = binary_dilation(m, square(3))
+        assert np.array_equal(out["morph_%02d_erode" % i], ndi.binary_erosion(m, structure=se, border_value=True))
+        assert np.array_equal(out["morph_%02d_dilate" % i], ndi.binary_dilation(m, structure=se))
+    return out
+
+
 def main():
     meta = {
         "python": sys.version.split()[0],
@@ -468,8 +512,12 @@ def main():
         "skimage": skimage.__version__,
         "reference": "ssilverman16/particle_col_image_segmentation @ /root/reference",
     }
+    if sys.argv[1:] == ["extensions"]:  # only the X1 / X2 fixtures (added after the others; leaves them untouched)
+        save("extensions", **ext_cases())
+        return
     with open(os.path.join(HERE, "VERSIONS.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
+    save("extensions", **ext_cases())
     save("primitives", **prim_cases())
     ct3 = {1: "3D05", 2: "Particle", 3: "Background"}
     ct5 = dict(synth.CELL_TYPES_5)

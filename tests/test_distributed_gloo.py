@@ -1,5 +1,12 @@
-"""N>1 path on CPU: world_size-2 gloo processes shard frames round-robin and all-gather their ROI tables; the
-gathered table must equal the single-process table whatever the number of ranks."""
+"""N>1 path on CPU: world_size-2 / -3 gloo processes shard the frames of a dataset round-robin, run them through
+``distributed.run_sharded`` and all-gather the tables; the gathered tables must equal the single-process tables
+whatever the number of ranks -- also when a rank owns no frame at all.
+
+The per-frame tables are REAL ones: ``tests/golden/sharded_tables.npz`` is what ``FramePipeline.tables()`` produced on
+an MI355X for an 11-frame dataset (``tests/golden/make_sharded_fixture.py``; ``tests/test_gpu_sharded.py`` checks on
+the GPU box that the file still matches the code).  No GPU here, so the pipeline object below only replays those rows
+for the frames it is handed -- everything else (sharding, batching, pipelined table take-over, empty-shard schema,
+``gather_tables`` / ``all_gather_table``) is the product code."""
 import os
 import socket
 
@@ -8,34 +15,45 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from particle_col_image_segmentation_amd.distributed import all_gather_table, gather_tables, run_sharded, shard_frames
+from conftest import GOLDEN
+from particle_col_image_segmentation_amd.distributed import TABLE_KEYS, all_gather_table, gather_tables, run_sharded, shard_frames
 
 
-def _fake_tables(frames):
-    """Deterministic per-frame tables (what FramePipeline.tables would give), built on CPU."""
-    rng_rows = []
-    roi_rows = []
-    frame_rows = []
-    for f in frames:
-        rng = np.random.default_rng(1000 + f)
-        n = 3 + f % 4
-        for l in range(n):
-            rng_rows.append([f, l + 1] + list(rng.random(5)))
-        for l in range(n + 2):
-            roi_rows.append([f, l + 1] + list(rng.random(3)))
-        frame_rows.append([f, n, n + 2])
-    return {"cells": np.array(rng_rows).reshape(-1, 7), "rois": np.array(roi_rows).reshape(-1, 5),
-            "frames": np.array(frame_rows, np.float64).reshape(-1, 3), "groups": np.zeros((0, 11))}
+def _fixture():
+    g = np.load(os.path.join(GOLDEN, "sharded_tables.npz"), allow_pickle=False)
+    return {k: g[k] for k in g.files}
 
 
-def _worker(rank, world, port, n_frames, out_dir):
+class _ReplayPipe:
+    """FramePipeline's table interface over the stored per-frame rows."""
+
+    def __init__(self):
+        self.fix = _fixture()
+
+    def run(self, ids):
+        return list(ids)
+
+    def table_columns(self, planes, ratios=None):
+        return {k: [str(c) for c in self.fix[k + "_columns"]] for k in TABLE_KEYS}
+
+    def tables(self, res, frame_ids=None):
+        assert list(res) == list(frame_ids)
+        out = {}
+        for k in TABLE_KEYS:
+            t = self.fix[k]
+            out[k] = np.concatenate([t[t[:, 0] == f] for f in frame_ids]) if len(frame_ids) else t[:0]
+            out[k + "_columns"] = [str(c) for c in self.fix[k + "_columns"]]
+        return out
+
+
+def _worker(rank, world, port, n_frames, batch, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    mine = shard_frames(n_frames, rank, world)
-    gathered = gather_tables(_fake_tables(mine))
+    gathered = run_sharded(n_frames, lambda ids: ids, _ReplayPipe(), batch=batch)
     if rank == 0:
-        np.savez(os.path.join(out_dir, "g%d.npz" % world), **{k: v for k, v in gathered.items() if isinstance(v, np.ndarray)})
+        np.savez(os.path.join(out_dir, "g%d_%d.npz" % (world, n_frames)),
+                 **{k: v for k, v in gathered.items() if isinstance(v, np.ndarray)})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -48,9 +66,16 @@ def _free_port():
     return p
 
 
+def _expected(n_frames):
+    """the single-process tables of frames 0 .. n_frames-1, in the gather's canonical (frame, label) order"""
+    fix = _fixture()
+    return gather_tables({k: fix[k][fix[k][:, 0] < n_frames] for k in TABLE_KEYS})
+
+
 def test_shard_frames_round_robin():
     assert shard_frames(10, 1, 4) == [1, 5, 9]
     assert sorted(sum((shard_frames(1000, r, 8) for r in range(8)), [])) == list(range(1000))
+    assert shard_frames(1, 1, 2) == []
 
 
 def test_single_process_gather_is_identity_sorted():
@@ -59,42 +84,34 @@ def test_single_process_gather_is_identity_sorted():
     assert out[:, :2].tolist() == [[0.0, 1.0], [0.0, 2.0], [2.0, 1.0]]
 
 
-def test_two_and_three_rank_gather_equals_single(tmp_path):
+def test_fixture_holds_real_rows():
+    fix = _fixture()
+    assert fix["rois"].shape[0] > 50 and fix["cells"].shape[0] > 20 and fix["frames"].shape[0] == 11
+    assert fix["groups"].shape[1] == 11 and fix["distances"].shape[1] == 3
+    assert list(fix["rois_columns"][:5]) == ["frame", "label", "area", "centroid_row", "centroid_col"]
+
+
+def test_run_sharded_without_process_group_equals_fixture():
+    got = run_sharded(11, lambda ids: ids, _ReplayPipe(), batch=4)
+    exp = _expected(11)
+    for k in TABLE_KEYS:
+        np.testing.assert_array_equal(got[k], exp[k])
+
+
+def test_two_and_three_ranks_equal_single_process(tmp_path):
     n_frames = 11
-    single = _fake_tables(range(n_frames))
+    exp = _expected(n_frames)
     for world in (2, 3):
-        mp.spawn(_worker, args=(world, _free_port(), n_frames, str(tmp_path)), nprocs=world, join=True)
-        g = np.load(str(tmp_path / ("g%d.npz" % world)))
-        for name in ("cells", "rois", "frames"):
-            np.testing.assert_array_equal(g[name], single[name])
+        mp.spawn(_worker, args=(world, _free_port(), n_frames, 3, str(tmp_path)), nprocs=world, join=True)
+        g = np.load(str(tmp_path / ("g%d_%d.npz" % (world, n_frames))))
+        for k in TABLE_KEYS:
+            np.testing.assert_array_equal(g[k], exp[k])
 
 
-class _FakePipe:
-    """Stands in for FramePipeline on CPU: run() just remembers the frame ids carried in the 'stack'."""
-
-    def run(self, stack):
-        return stack
-
-    def tables(self, res, frame_ids=None):
-        assert list(res) == list(frame_ids)
-        return _fake_tables(frame_ids)
-
-
-def _worker_sharded(rank, world, port, n_frames, out_dir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    gathered = run_sharded(n_frames, lambda ids: ids, _FakePipe(), batch=3)
-    if rank == 0:
-        np.savez(os.path.join(out_dir, "s%d.npz" % world), **{k: v for k, v in gathered.items() if isinstance(v, np.ndarray)})
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_run_sharded_two_ranks_equals_single(tmp_path):
-    n_frames = 10
-    single = _fake_tables(range(n_frames))
-    mp.spawn(_worker_sharded, args=(2, _free_port(), n_frames, str(tmp_path)), nprocs=2, join=True)
-    g = np.load(str(tmp_path / "s2.npz"))
-    for name in ("cells", "rois", "frames"):
-        np.testing.assert_array_equal(g[name], single[name])
+def test_rank_without_frames_joins_the_same_collectives(tmp_path):
+    """n_frames < world: rank 1 owns nothing and must still enter every all-gather with the right column counts."""
+    exp = _expected(1)
+    mp.spawn(_worker, args=(2, _free_port(), 1, 64, str(tmp_path)), nprocs=2, join=True)
+    g = np.load(str(tmp_path / "g2_1.npz"))
+    for k in TABLE_KEYS:
+        np.testing.assert_array_equal(g[k], exp[k])

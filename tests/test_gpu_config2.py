@@ -1,0 +1,46 @@
+"""BASELINE config 2 at its real shape: the exact batch ``bench.py`` times (64 frames of 1024x1024x5 from
+``synth.gen_batch_torch(10_000, ...)``) and its quantised variant (``bench.py --levels 100``), every frame against the
+CPU oracle: class-component mask, recreated class map and refined ROI mask bit-exact, ROI plane sums <= 1e-6 relative
+(north_star tolerance; the float64 atomics differ from the oracle's summation order by ~1e-15)."""
+import pytest
+
+from oracle import parity
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _run_and_compare(stack, ct):
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline
+    pipe = FramePipeline(ct)
+    res = pipe.run(stack)
+    res.synchronize()
+    assert int(res["overflow"].sum()) == 0 and int(res["ws_overflow"].sum()) == 0
+    refs, wall, procs = parity.run_oracle(stack.cpu().numpy(), ct)
+    n = parity.compare(res, range(stack.shape[0]), refs, sums_rtol=1e-6)
+    assert n == stack.shape[0]
+    return res, refs
+
+
+def test_bench_batch_64x1024_tie_free_all_frames():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the HIP path has no CPU fallback")
+    from particle_col_image_segmentation_amd import synth
+    ct = dict(synth.CELL_TYPES_5)
+    stack = synth.gen_batch_torch(10_000, 64, 1024, 1024, torch.device("cuda", 0))
+    res, refs = _run_and_compare(stack, ct)
+    # the tie-free variant must not need the sequential fallback on more than a handful of frames (float32 collisions)
+    assert int(res["tie_flags"].sum()) <= 8
+
+
+def test_bench_batch_quantised_boundary_plane():
+    """``bench.py --levels 100``: the boundary plane as k/100 vote fractions -- equal-valued seeds and plateaus in
+    every frame, i.e. the watershed's exact path."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from particle_col_image_segmentation_amd import synth
+    ct = dict(synth.CELL_TYPES_5)
+    stack = synth.gen_batch_torch(10_000, 8, 1024, 1024, torch.device("cuda", 0))
+    stack[:, 3] = torch.round(stack[:, 3] * 100) / 100
+    res, refs = _run_and_compare(stack, ct)
+    assert int(res["tie_flags"].sum()) >= 1  # otherwise this test does not exercise what it says

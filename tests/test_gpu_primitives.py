@@ -316,6 +316,29 @@ def test_refine_chain_batch(ops):
             np.testing.assert_array_equal(host(labels)[i], ref["labels"])
 
 
+def test_label_regions_fused_equals_two_step(ops):
+    """pcseg_label_regions_u8 (numbering decoded inside the reduction) against label + region_reduce, on widths that
+    take the fused kernel (W % 4 == 0) and on one that takes the two-step fallback."""
+    from particle_col_image_segmentation_amd import synth
+    for (H, W) in ((160, 192), (97, 132), (64, 130), (33, 64)):
+        st = synth.gen_batch(70, 3, H, W)
+        cm = np.stack([orc.median_filter(c) for c in synth.class_map_from_stack(st)])
+        labels, counts = ops.label_equal8(dev(cm))
+        stats, cls_out, sums, ovf = ops.region_reduce(labels, counts, cls=dev(cm), planes=dev(st), cap=4096, sum_classes=0b110)
+        l2, c2, s2, co2, su2, ov2 = ops.label_regions(dev(cm), planes=dev(st), cap=4096, sum_classes=0b110)
+        assert torch.equal(l2, labels) and torch.equal(c2, counts) and int(ov2.sum()) == 0
+        for b in range(3):
+            n = int(counts[b])
+            np.testing.assert_array_equal(host(l2)[b], orc.label(cm[b]))
+            assert torch.equal(s2[b, :n], stats[b, :n]) and torch.equal(co2[b, :n], cls_out[b, :n])
+            np.testing.assert_allclose(host(su2)[b, :n], host(sums)[b, :n], rtol=1e-12, atol=0)
+        # without planes, and with a capacity that is too small
+        l3, c3, s3, co3, su3, ov3 = ops.label_regions(dev(cm), cap=4096)
+        assert su3 is None and torch.equal(l3, labels) and all(torch.equal(s3[b, :int(counts[b])], stats[b, :int(counts[b])]) for b in range(3))
+        l4, c4, s4, co4, su4, ov4 = ops.label_regions(dev(cm), cap=2)
+        assert torch.equal(l4, labels) and int(ov4.min()) == 1
+
+
 def test_merge_groups(ops):
     from particle_col_image_segmentation_amd import synth
     st = synth.gen_batch(90, 2, 160, 160)
@@ -342,6 +365,15 @@ def test_merge_groups(ops):
     np.testing.assert_array_equal(host(roots) >= 0, host(dil).astype(bool))
     g2, n2 = ops.merge_groups(roots, stats, dev(rl), n_list, roots=True)
     assert torch.equal(g2, group_of) and torch.equal(n2, n_groups)
+    # run-based path (what the pipeline uses): no label image at all, components looked up through the bit words
+    dbits, run_par = ops.dilated_runs(dev(cm), (1 << 1) | (1 << 2), 2)
+    words = host(dbits).view(np.uint32)
+    for i in range(2):
+        H_, W_ = cm[i].shape
+        unpacked = ((words[i][:, None, :] >> np.arange(32, dtype=np.uint32)[None, :, None]) & 1).reshape(-1, W_)[:H_]
+        np.testing.assert_array_equal(unpacked.astype(bool), host(dil)[i].astype(bool))
+    g3, n3 = ops.merge_groups_runs(dbits, run_par, stats, dev(rl), n_list)
+    assert torch.equal(g3, group_of) and torch.equal(n3, n_groups)
     for rad in (0, 1, 3, 5):
         rr = ops.dilated_roots(dev(cm), 1 << 1, rad)
         for i in range(2):
@@ -365,21 +397,42 @@ def test_remove_overlapping(ops):
 
 
 def test_extensions_otsu_morph(ops):
-    """north_star extensions without a reference call site: checked against the oracle only (parity unpinned)."""
+    """north_star extensions X1 / X2: no reference call site, so the libraries SURVEY.md 8a names are the pin
+    (skimage.filters.threshold_otsu, skimage / scipy 3x3 binary erosion and dilation; tests/golden/extensions.npz),
+    plus the oracle on a batch (frames of one launch keep their own [min, max])."""
+    g = load_golden("extensions")
+    i = 0
+    while "otsu_%02d_inp" % i in g.files:
+        img = g["otsu_%02d_inp" % i]
+        thr, hist, lohi = ops.threshold_otsu(dev(img[None]), return_hist=True)
+        assert float(thr[0]) == float(g["otsu_%02d_thr" % i]), i  # bit-exact float32 bin centre
+        if "otsu_%02d_hist" % i in g.files:
+            np.testing.assert_array_equal(host(hist)[0], g["otsu_%02d_hist" % i])
+        assert float(lohi[0, 0]) == img.min() and float(lohi[0, 1]) == img.max()
+        i += 1
+    assert i >= 6
+    i = 0
+    while "morph_%02d_inp" % i in g.files:
+        m = g["morph_%02d_inp" % i]
+        np.testing.assert_array_equal(host(ops.morph3x3(dev(m[None]), 1))[0].astype(bool), g["morph_%02d_erode" % i])
+        np.testing.assert_array_equal(host(ops.morph3x3(dev(m[None]), 0))[0].astype(bool), g["morph_%02d_dilate" % i])
+        i += 1
+    assert i >= 6
     m = RNG.random((2, 50, 70)) < 0.5
     for erode in (0, 1):
         got = host(ops.morph3x3(dev(m), erode))
-        for i in range(2):
-            np.testing.assert_array_equal(got[i].astype(bool), orc.morph3x3(m[i], erode))
-    img = RNG.random((2, 100, 90)).astype(np.float32)
-    hist, lohi = ops.otsu_hist(dev(img))
-    for i in range(2):
-        thr, h = orc.threshold_otsu(img[i])
-        np.testing.assert_array_equal(host(hist)[i], h)
-        assert float(lohi[i, 0]) == img[i].min() and float(lohi[i, 1]) == img[i].max()
-    thr = ops.threshold_otsu(dev(img))
-    for i in range(2):
-        assert abs(thr[i] - orc.threshold_otsu(img[i])[0]) < 1e-12
+        for k in range(2):
+            np.testing.assert_array_equal(got[k].astype(bool), orc.morph3x3(m[k], erode))
+    img = RNG.random((3, 100, 90)).astype(np.float32)
+    img[1] *= 37.0
+    img[2] = 0.25
+    thr, hist, lohi = ops.threshold_otsu(dev(img), return_hist=True)
+    h2, lohi2 = ops.otsu_hist(dev(img))
+    assert torch.equal(hist, h2) and torch.equal(lohi, lohi2)
+    for k in range(3):
+        t, h = orc.threshold_otsu(img[k])
+        assert float(thr[k]) == t
+        np.testing.assert_array_equal(host(hist)[k], h)
 
 
 def test_watershed_proof_holds_on_adversarial_ties(ops):

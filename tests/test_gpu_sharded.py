@@ -1,0 +1,84 @@
+"""BASELINE configs 3 / 5 code path on one GPU: ``distributed.run_sharded`` with the REAL pipeline (world size 1,
+several batches incl. a partial one) against per-frame oracle tables; and the fixture the CPU gloo tests shard."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle as orc
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def test_run_sharded_real_pipeline_matches_per_frame_oracle():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the HIP path has no CPU fallback")
+    from particle_col_image_segmentation_amd import synth
+    from particle_col_image_segmentation_amd.distributed import run_sharded
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline, RATIOS_5
+    ct = dict(synth.CELL_TYPES_5)
+    n_frames, H, W = 130, 128, 128
+    frames = {i: synth.gen_frame(5000 + i, H, W, ties=(i % 5 == 4)) for i in range(n_frames)}
+    make_batch = lambda ids: torch.from_numpy(np.stack([frames[i] for i in ids])).cuda()
+    pipe = FramePipeline(ct)
+    tabs = run_sharded(n_frames, make_batch, pipe, batch=48, check=False)
+    rois, cells, fr = tabs["rois"], tabs["cells"], tabs["frames"]
+    assert fr.shape[0] == n_frames and list(fr[:, 0]) == list(range(n_frames))
+    names = pipe.tables_.slot_names
+    n_nan = 0
+    for i in range(n_frames):
+        rf = orc.refine_boundaries(frames[i][3])
+        exp, _ = orc.roi_activity_table(rf["labels"], frames[i], ratios=RATIOS_5)
+        m = int(rf["markers"].max())
+        st = orc.region_table(rf["labels"], m)
+        st = st[st[:, 0] > 0]
+        rows = rois[rois[:, 0] == i]
+        assert rows.shape[0] == exp.shape[0] == st.shape[0], i
+        np.testing.assert_array_equal(rows[:, 1], exp[:, 1])
+        np.testing.assert_array_equal(rows[:, 2], st[:, 0])
+        np.testing.assert_array_equal(rows[:, 3], st[:, 1] / st[:, 0])
+        np.testing.assert_array_equal(rows[:, 4], st[:, 2] / st[:, 0])
+        np.testing.assert_allclose(rows[:, 5:10], exp[:, 2:7], rtol=1e-9)
+        np.testing.assert_allclose(rows[:, 10:12], exp[:, 7:9], rtol=1e-6)
+        assert fr[i, 2] == m
+        try:
+            ref = orc.segment_frame(frames[i], ct, merged=False)
+        except ValueError:
+            n_nan += 1
+            continue
+        crow = cells[cells[:, 0] == i]
+        exp_regs = []
+        for s, name in enumerate(names):
+            exp_regs += [(r.label, 1, r.area, 1) for r in ref["cell_pos"].get(name, [])]
+            exp_regs += [(r.label, 2, r.area, r.cells) for r in ref["cell_clusters"].get(name, [])]
+        exp_regs.sort()
+        assert [(int(r[1]), int(r[3]), int(r[4]), int(r[11])) for r in crow] == exp_regs, i
+        cnt, dens, ratio = ref["counts"]
+        cols = tabs["frames_columns"]
+        for name in cnt:
+            assert fr[i, cols.index(name + "_count")] == cnt[name]
+            assert fr[i, cols.index(name + "_density")] == dens[name]
+            assert fr[i, cols.index(name + "_area_ratio")] == ratio[name]
+    assert n_nan < n_frames // 2
+
+
+def test_sharded_fixture_is_what_the_pipeline_produces():
+    """tests/golden/sharded_tables.npz (what the CPU gloo tests shard) must be exactly what this code produces."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    spec = importlib.util.spec_from_file_location("make_sharded_fixture", os.path.join(GOLDEN, "make_sharded_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fresh = mod.make()
+    stored = np.load(os.path.join(GOLDEN, "sharded_tables.npz"), allow_pickle=False)
+    assert sorted(stored.files) == sorted(fresh)
+    for k in stored.files:
+        if k.endswith("_columns"):
+            assert list(stored[k]) == list(fresh[k])
+        elif k in ("cells", "rois"):  # float64 atomics: plane sums may differ in the last bits between runs
+            np.testing.assert_allclose(fresh[k], stored[k], rtol=1e-12, atol=0)
+        else:
+            np.testing.assert_array_equal(fresh[k], stored[k])

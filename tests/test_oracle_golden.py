@@ -160,3 +160,24 @@ def test_overlap_removal():
     for i in range(2):
         out = orc.combine_cell_positions_and_clusters(g["ov_%d_dapi" % i], g["ov_%d_other" % i])
         np.testing.assert_array_equal(out, g["ov_%d_out" % i])
+
+
+def test_extensions_otsu_and_morph3x3_against_the_libraries():
+    """X1 / X2 (north_star extensions): skimage.filters.threshold_otsu and the 3x3 binary erosion / dilation of
+    skimage.morphology (= scipy.ndimage with the same border values), captured by make_golden.py (extensions.npz)."""
+    g = load_golden("extensions")
+    i = 0
+    while "otsu_%02d_inp" % i in g.files:
+        thr, hist = orc.threshold_otsu(g["otsu_%02d_inp" % i])
+        assert thr == float(g["otsu_%02d_thr" % i]), i  # bit-exact: the library's float32 bin centre
+        if "otsu_%02d_hist" % i in g.files:
+            np.testing.assert_array_equal(hist, g["otsu_%02d_hist" % i])
+        i += 1
+    assert i >= 6
+    i = 0
+    while "morph_%02d_inp" % i in g.files:
+        m = g["morph_%02d_inp" % i]
+        np.testing.assert_array_equal(orc.morph3x3(m, 1), g["morph_%02d_erode" % i])
+        np.testing.assert_array_equal(orc.morph3x3(m, 0), g["morph_%02d_dilate" % i])
+        i += 1
+    assert i >= 6

@@ -1,0 +1,31 @@
+"""The parity helper used by the GPU tests and by bench.py's cpu_baseline leg: its worker digests must describe what
+``oracle.segment_frame`` returns (CPU only; two spawn workers)."""
+import numpy as np
+
+from oracle import oracle as orc
+from oracle import parity
+from particle_col_image_segmentation_amd import synth
+
+
+def test_run_oracle_matches_direct_call():
+    ct = dict(synth.CELL_TYPES_5)
+    stacks = synth.gen_batch(300, 2, 96, 80)
+    refs, wall, procs = parity.run_oracle(stacks, ct, processes=2)
+    assert procs == 2 and wall > 0 and len(refs) == 2
+    for st, ref in zip(stacks, refs):
+        try:
+            direct = orc.segment_frame(st, ct)
+        except ValueError:
+            assert ref["nan"]
+            continue
+        assert not ref["nan"]
+        assert ref["labels"] == parity._digest(direct["label_im"], np.int32)
+        assert ref["ws_labels"] == parity._digest(direct["refine"]["labels"], np.int32)
+        assert ref["denoised"] == parity._digest(direct["denoised"], np.uint8)
+        assert ref["recreated"] == parity._digest(direct["recreated"], np.uint8)
+        assert ref["n_labels"] == int(direct["label_im"].max())
+        np.testing.assert_array_equal(ref["roi_sums"], direct["roi_sums"])
+        # a digest is sensitive to a single changed pixel
+        changed = direct["label_im"].copy()
+        changed[0, 0] += 1
+        assert parity._digest(changed, np.int32) != ref["labels"]
