@@ -70,6 +70,15 @@ int pcseg_argmax_planes_f32(const float *stack, uint8_t *cls, int B, int C, int 
  * (tiff_analysis.py:122, 643) */
 int pcseg_median5_u8(const uint8_t *in, uint8_t *out, int B, int H, int W, pcseg_stream_t stream);
 
+/* ---- ingest + A1 + A2 in one call: class map (argmax + 1) -> median_filter(size=5) -> label(z_slice)
+ * (tiff_analysis.py:639-643, 743).  Same results as pcseg_argmax_planes_f32, pcseg_median5_u8, pcseg_ccl8_equal_u8 in
+ * sequence, but for C <= 5 planes the three tile passes are ONE kernel: the raw class map is never written, the medians
+ * are labelled while they sit in LDS.  denoised: uint8 (B,H,W) = the median-filtered class map (what the reference
+ * calls ds_arr / z_slice); labels / counts as pcseg_ccl8_equal_u8. */
+size_t pcseg_classmap_label_workspace_bytes(int B, int H, int W);
+int pcseg_classmap_label_f32(const float *stack, int C, uint8_t *denoised, int32_t *labels, int32_t *counts,
+                             int B, int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
 /* ---- A2: skimage.measure.label (tiff_analysis.py:743, 260, 829;
  * refine_boundaries.py:64) and scipy.ndimage.label (inside binary_fill_holes).
  * labels: int32 (B,H,W), 0 = background, 1..N in raster order of each
@@ -106,17 +115,6 @@ int pcseg_region_reduce_n(const int32_t *labels, const int32_t *counts, const ui
 int pcseg_region_reduce_sel(const int32_t *labels, const int32_t *counts, const uint8_t *cls, uint64_t sum_class_bits,
                             const float *planes, int C, int B, int H, int W, int cap, int64_t *stats,
                             uint8_t *cls_out, double *sums, int32_t *overflow, pcseg_stream_t stream);
-
-/* ---- A2 + A3 (+ M1) in one call: label(z_slice) and its regionprops table (tiff_analysis.py:743, 746-773).
- * The same results as pcseg_ccl8_equal_u8 followed by pcseg_region_reduce_sel(labels, counts, cls = in, ...), but the
- * numbering pass and the reduction are one kernel: every pixel's label is decoded from its union-find root while the
- * table is accumulated, the label image is written once and never read back.  Workspace:
- * pcseg_label_regions_workspace_bytes. */
-size_t pcseg_label_regions_workspace_bytes(int B, int H, int W);
-int pcseg_label_regions_u8(const uint8_t *in, uint64_t sum_class_bits, const float *planes, int C, int32_t *labels,
-                           int32_t *counts, int B, int H, int W, int cap, int64_t *stats, uint8_t *cls_out,
-                           double *sums, int32_t *overflow, void *workspace, size_t workspace_bytes,
-                           pcseg_stream_t stream);
 
 /* ---- R1: binary_mask = boundary_map < threshold (refine_boundaries.py:44-45) */
 int pcseg_threshold_lt_f32(const float *img, float threshold, uint8_t *mask, int B, int H, int W,

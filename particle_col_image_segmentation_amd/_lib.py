@@ -27,6 +27,8 @@ SIGNATURES = {
     "pcseg_timing_report": (c_int, [c_char_p, c_size_t]),
     "pcseg_argmax_planes_f32": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "pcseg_median5_u8": (c_int, [_P, _P, _I, _I, _I, _P]),
+    "pcseg_classmap_label_workspace_bytes": (c_size_t, [_I, _I, _I]),
+    "pcseg_classmap_label_f32": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_ccl_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_ccl8_equal_u8": (c_int, [_P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_ccl8_bool": (c_int, [_P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
@@ -35,8 +37,6 @@ SIGNATURES = {
     "pcseg_region_reduce": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "pcseg_region_reduce_n": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "pcseg_region_reduce_sel": (c_int, [_P, _P, _P, ctypes.c_uint64, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
-    "pcseg_label_regions_workspace_bytes": (c_size_t, [_I, _I, _I]),
-    "pcseg_label_regions_u8": (c_int, [_P, c_uint64, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, c_size_t, _P]),
     "pcseg_threshold_lt_f32": (c_int, [_P, c_float, _P, _I, _I, _I, _P]),
     "pcseg_edt_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_edt_sq_u8": (c_int, [_P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),

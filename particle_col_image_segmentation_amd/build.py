@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["stencil.hip", "ccl.hip", "reduce.hip", "edt.hip", "watershed.hip", "tables.hip"]
+SOURCES = ["stencil.hip", "ccl.hip", "reduce.hip", "edt.hip", "watershed.hip", "tables.hip", "frontend.hip"]
 LIB = os.path.join(HERE, "libpcseg.so")
 
 
@@ -13,7 +13,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h"]]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h", "tile_ops.h"]]
     deps.append(os.path.join(HERE, "..", "include", "pcseg.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -12,11 +12,10 @@
 #include <type_traits>
 
 #include "common.h"
+#include "tile_ops.h"
 
 namespace pcseg {
 
-constexpr int CCL_TW = 64, CCL_TH = 32, CCL_TILE = CCL_TW * CCL_TH;
-static_assert(CCL_TH == 32 && CCL_TW == 64, "the tile pass assumes one 64-lane row per trip and one 32-row bit word per column");
 constexpr int SCAN_PIX = 1024;  // pixels per block in the count / assign / relabel passes
 
 // ---- key functors: key(b, r, c) of pixel (r, c) of frame b; 0 = background, equal non-zero keys connect
@@ -82,41 +81,8 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(KeyFn keyfn, int *__restr
         }
     }
     __syncthreads();
-    // row runs are pre-linked without atomics: a wave covers one 64-pixel tile row per trip (CCL_TW == 64), run heads
-    // come from a ballot and every pixel points straight at its run's first pixel (chains of length 1, not 64)
-    for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
-        const int k = key[i], lc = i % CCL_TW;
-        const bool head = lc == 0 || key[i - 1] != k;
-        const unsigned long long heads = __ballot(head);
-        const unsigned long long upto = heads & (lc == 63 ? ~0ull : ((2ull << lc) - 1ull));
-        const int start = 63 - __clzll((long long)upto);
-        par[i] = k == 0 ? -1 : (i - lc + start);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
-        int k = key[i], lc = i % CCL_TW;
-        if (k == 0 || i < CCL_TW) continue;
-        bool w = lc > 0 && key[i - 1] == k;
-        bool n = key[i - CCL_TW] == k;
-        bool nw = lc > 0 && key[i - CCL_TW - 1] == k;
-        if (n && !(w && nw)) unite_lds(par, i, i - CCL_TW);
-        if (CONN8) {
-            bool ne = lc < CCL_TW - 1 && key[i - CCL_TW + 1] == k;
-            if (ne && !n) unite_lds(par, i, i - CCL_TW + 1);
-            if (nw && !n && !w) unite_lds(par, i, i - CCL_TW - 1);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
-        int r = r0 + i / CCL_TW, c = c0 + i % CCL_TW;
-        if (r >= H || c >= W) continue;
-        int v = -1;
-        if (key[i] != 0) {
-            int root = find_lds(par, i);
-            v = (r0 + root / CCL_TW) * W + c0 + root % CCL_TW;
-        }
-        parent[fbase + (int64_t)r * W + c] = v;
-    }
+    ccl_tile_unions<CONN8>(key, par);
+    ccl_tile_store(key, par, parent, fbase, r0, c0, H, W);
 }
 
 // Threads enumerate the tile-border pixels densely (a per-pixel grid would leave one or two working lanes per wave,
@@ -364,29 +330,36 @@ static int ccl_full(KeyFn keyfn, int32_t *labels, int32_t *counts, int B, int H,
     return ccl_compact(ws.parent, ws.blockcount, ws.nblk, labels, counts, PredAll(), true, B, H, W, s);
 }
 
-int ccl_equal_u8_roots_and_ranks(const uint8_t *in, int *codes, int *counts, int **parent, int **blockoff, int *nblk, int B, int H,
-                                 int W, void *workspace, size_t workspace_bytes, hipStream_t s)
+int ccl_plan(void *workspace, size_t workspace_bytes, int B, int H, int W, CclPlan *plan, const char *who)
 {
-    static_assert(SCAN_PIX == 1024, "region_reduce_col_kernel<.., true> decodes with blocks of 1024 pixels");
     Carver cv(workspace, workspace_bytes);
     CclWs ws = ccl_carve(cv, B, H, W);
     if (!cv.ok()) {
-        set_error("label_regions: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        set_error("%s: workspace too small (%zu < %zu)", who, workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
     }
-    int rc = ccl_roots<KeyEqU8, true>(KeyEqU8{in, W, (int64_t)H * W}, ws.parent, B, H, W, s);
-    if (rc) return rc;
-    // roots are exact after the border pass (parent[i] == i): count and rank them without flattening anything
-    const int64_t n = (int64_t)H * W;
-    PCSEG_LAUNCH((ccl_flatten_count_kernel<PredAll>), dim3(ws.nblk, B), dim3(256), 0, s, ws.parent, codes, ws.blockcount, PredAll(), n,
-                 ws.nblk, false);
-    PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, ws.blockcount, counts, ws.nblk);
-    PCSEG_CHECK_LAUNCH();
-    *parent = ws.parent;
-    *blockoff = ws.blockcount;
-    *nblk = ws.nblk;
+    plan->parent = ws.parent;
+    plan->blockcount = ws.blockcount;
+    plan->nblk = ws.nblk;
     return PCSEG_OK;
+}
+
+int ccl_equal_u8_finish(const uint8_t *in, const CclPlan &plan, bool tile_pass_done, int *labels, int *counts, int B, int H, int W,
+                        hipStream_t s)
+{
+    const KeyEqU8 keyfn{in, W, (int64_t)H * W};
+    dim3 tgrid((W + CCL_TW - 1) / CCL_TW, (H + CCL_TH - 1) / CCL_TH, B);
+    if (!tile_pass_done) {
+        PCSEG_LAUNCH((ccl_tile_kernel<KeyEqU8, true>), tgrid, dim3(256), 0, s, keyfn, plan.parent, H, W);
+        PCSEG_CHECK_LAUNCH();
+    }
+    if (tgrid.x > 1 || tgrid.y > 1) {
+        const int64_t border_px = (int64_t)((H - 1) / CCL_TH) * W + (int64_t)2 * ((W - 1) / CCL_TW) * H;
+        dim3 bgrid((unsigned)((border_px + 255) / 256), B);
+        PCSEG_LAUNCH((ccl_border_kernel<KeyEqU8, true>), bgrid, dim3(256), 0, s, keyfn, plan.parent, H, W);
+        PCSEG_CHECK_LAUNCH();
+    }
+    return ccl_compact(plan.parent, plan.blockcount, plan.nblk, labels, counts, PredAll(), true, B, H, W, s);
 }
 
 // ---- roots(+1) image -> parent(-1 bg) conversion for pcseg_compact_labels
@@ -443,10 +416,8 @@ __global__ void __launch_bounds__(256) set_bits4_kernel(const uint8_t *__restric
 
 // out = dilate(in, disk(radius)): for every row offset dy the columns within half(dy) = floor(sqrt(r^2 - dy^2)) are
 // OR-ed, then shifted by dy rows across the 32-row words (skimage disk: x^2 + y^2 <= r^2; outside the image = 0)
-// run_parent != nullptr: every vertical run of set bits of the result (a run never leaves its 32-row word) becomes a
-// union-find node named by its top pixel; the node is initialised here, bitrun_link_kernel adds the links.
 __global__ void __launch_bounds__(256) dilate_bits_kernel(const unsigned *__restrict__ in, unsigned *__restrict__ out,
-                                                           int radius, int H, int W, int nch, int *__restrict__ run_parent)
+                                                           int radius, int H, int W, int nch)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int ch = blockIdx.y, b = blockIdx.z;
@@ -475,71 +446,128 @@ __global__ void __launch_bounds__(256) dilate_bits_kernel(const unsigned *__rest
     const int rows = min(32, H - ch * 32);
     if (rows < 32) acc &= (1u << rows) - 1u;
     out[((int64_t)b * nch + ch) * W + c] = acc;
-    if (run_parent) {
-        unsigned heads = acc & ~(acc << 1);
-        int *par = run_parent + (int64_t)b * H * W;
-        while (heads) {
-            const int j = __ffs(heads) - 1;
-            heads &= heads - 1;
-            const int node = (ch * 32 + j) * W + c;
-            par[node] = node;
-        }
-    }
 }
 
 // ---- components of a 1-bit image from its vertical runs (A6: label(dilated mask), tiff_analysis.py:829) ----------
 // The dilated masks of the merge step are only ever LOOKED UP at a few hundred centroid pixels per frame, so no label
-// image is made: the nodes of the union-find are the vertical runs of set bits (named by their top pixel, a few per
-// cent of the pixel count) and only their entries of the pixel-indexed parent array are ever touched.  One thread
-// per 32-row word: each of its runs is linked (8-connectivity) to the runs of the word in the column to the left that
-// overlap rows [top - 1, bottom + 1], and a run that starts in row 0 of the word to the runs that end in row 31 of
-// the three words above (columns c - 1, c, c + 1).  Every adjacent pair of set pixels is covered by one of these
-// rules seen from the right / lower pixel.
+// image is made: the nodes of the union-find are the vertical runs of set bits (a run never leaves its 32-row word; it
+// is named by its top pixel; runs are a few per cent of the pixel count) and only their entries of the pixel-indexed
+// parent array are ever touched.  Two passes: an LDS union-find per tile of 64 columns x 128 rows (four words per
+// column), then the links that cross a tile edge with agent-scope atomics.  Links (8-connectivity), always seen from
+// the right / lower pixel: a run to the runs of the column to its left that overlap rows [top - 1, bottom + 1]; a
+// run that starts in row 0 of its word to the run that ends in row 31 of the word above -- or, if that pixel is not
+// set, to the two diagonal ones (with the vertical link present the diagonals are implied by the left links of the row
+// above).
+constexpr int BR_TW = 64, BR_CH = 4, BR_ROWS = 32 * BR_CH;
+
 __device__ __forceinline__ int bitrun_start(unsigned word, int p)  // first row of the run of `word` that contains bit p
 {
     const unsigned below = ~word & ((1u << p) - 1u);
     return below ? 32 - __clz(below) : 0;
 }
 
-__global__ void __launch_bounds__(256) bitrun_link_kernel(const unsigned *__restrict__ bits, int *__restrict__ parent, int H, int W,
+// calls link(top row of a run of w, top row of a run of wl) for every pair of runs that touch across the column edge
+template <typename Link>
+__device__ __forceinline__ void bitrun_left_links(unsigned w, unsigned wl, Link &&link)
+{
+    unsigned rest = wl ? w : 0u;
+    while (rest) {
+        const int a = __ffs(rest) - 1;  // top of this run of w
+        const unsigned from_a = w >> a;
+        const int len = from_a == 0xFFFFFFFFu ? 32 : __ffs(~from_a) - 1;
+        const int e = a + len - 1;  // bottom
+        rest = e >= 31 ? 0u : rest & ~((2u << e) - 1u);
+        const int lo = max(a - 1, 0), hi = min(e + 1, 31);
+        unsigned m = wl & (hi == 31 ? 0xFFFFFFFFu : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
+        while (m) {
+            const int p = __ffs(m) - 1;
+            const int st = bitrun_start(wl, p);
+            const unsigned from_p = wl >> p;
+            const int run_len = from_p == 0xFFFFFFFFu ? 32 : __ffs(~from_p) - 1;
+            const int en = p + run_len - 1;
+            m = en >= 31 ? 0u : m & ~((2u << en) - 1u);
+            link(a, st);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) bitrun_tile_kernel(const unsigned *__restrict__ bits, int *__restrict__ parent, int H, int W,
                                                            int nch)
+{
+    __shared__ unsigned sw[BR_CH][BR_TW];
+    __shared__ int lpar[BR_ROWS * BR_TW];  // node = (row inside the tile) * 64 + column; only run tops are used
+    const int col = threadIdx.x & (BR_TW - 1), q = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * BR_TW, ch0 = blockIdx.y * BR_CH, b = blockIdx.z;
+    const int c = c0 + col, ch = ch0 + q;
+    const unsigned w = (c < W && ch < nch) ? bits[((int64_t)b * nch + ch) * W + c] : 0u;
+    sw[q][col] = w;
+    for (unsigned heads = w & ~(w << 1); heads; heads &= heads - 1) {
+        const int node = (q * 32 + (__ffs(heads) - 1)) * BR_TW + col;
+        lpar[node] = node;
+    }
+    __syncthreads();
+    if (w) {
+        if (col > 0)
+            bitrun_left_links(w, sw[q][col - 1], [&](int a, int st) {
+                unite_lds(lpar, (q * 32 + a) * BR_TW + col, (q * 32 + st) * BR_TW + col - 1);
+            });
+        if ((w & 1u) && q > 0) {
+            const int node = (q * 32) * BR_TW + col;
+            const unsigned wu = sw[q - 1][col];
+            if (wu >> 31) {
+                unite_lds(lpar, node, ((q - 1) * 32 + bitrun_start(wu, 31)) * BR_TW + col);
+            } else {
+                if (col > 0 && (sw[q - 1][col - 1] >> 31))
+                    unite_lds(lpar, node, ((q - 1) * 32 + bitrun_start(sw[q - 1][col - 1], 31)) * BR_TW + col - 1);
+                if (col + 1 < BR_TW && (sw[q - 1][col + 1] >> 31))
+                    unite_lds(lpar, node, ((q - 1) * 32 + bitrun_start(sw[q - 1][col + 1], 31)) * BR_TW + col + 1);
+            }
+        }
+    }
+    __syncthreads();
+    int *par = parent + (int64_t)b * H * W;
+    for (unsigned heads = w & ~(w << 1); heads; heads &= heads - 1) {
+        const int node = (q * 32 + (__ffs(heads) - 1)) * BR_TW + col;
+        const int root = find_lds(lpar, node);
+        par[(ch0 * 32 + node / BR_TW) * W + c0 + node % BR_TW] = (ch0 * 32 + root / BR_TW) * W + c0 + root % BR_TW;
+    }
+}
+
+// links that cross a tile edge: the left links of a tile's first column, the upward links of a tile's first word
+// (all three columns c - 1, c, c + 1 of the word above lie in other tiles' rows), and the diagonal upward links of the
+// first / last column of a tile whose neighbour column lies in the tile to the left / right
+__global__ void __launch_bounds__(256) bitrun_border_kernel(const unsigned *__restrict__ bits, int *__restrict__ parent, int H, int W,
+                                                             int nch)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int ch = blockIdx.y, b = blockIdx.z;
     if (c >= W) return;
+    const int col = c & (BR_TW - 1);
+    const bool tile_left = col == 0 && c > 0, tile_top = (ch % BR_CH) == 0 && ch > 0;
+    const bool edge_col = col == 0 || col == BR_TW - 1;
+    if (!tile_left && !tile_top && !(edge_col && ch > 0)) return;
     const unsigned *wb = bits + (int64_t)b * nch * W;
     const unsigned w = wb[(int64_t)ch * W + c];
     if (w == 0) return;
     int *par = parent + (int64_t)b * H * W;
     const int row0 = ch * 32;
-    if (c > 0) {
-        const unsigned wl = wb[(int64_t)ch * W + c - 1];
-        unsigned rest = wl ? w : 0u;
-        while (rest) {
-            const int a = __ffs(rest) - 1;                       // top of this run of w
-            const unsigned from_a = w >> a;
-            const int len = from_a == 0xFFFFFFFFu ? 32 : __ffs(~from_a) - 1;
-            const int e = a + len - 1;                           // bottom
-            rest = e >= 31 ? 0u : rest & ~((2u << e) - 1u);
-            const int lo = max(a - 1, 0), hi = min(e + 1, 31);
-            unsigned m = wl & (hi == 31 ? 0xFFFFFFFFu : ((2u << hi) - 1u)) & ~((1u << lo) - 1u);
-            const int node = (row0 + a) * W + c;
-            while (m) {
-                const int p = __ffs(m) - 1;
-                const int st = bitrun_start(wl, p);
-                const unsigned from_p = wl >> p;
-                const int run_len = from_p == 0xFFFFFFFFu ? 32 : __ffs(~from_p) - 1;
-                const int en = p + run_len - 1;
-                m = en >= 31 ? 0u : m & ~((2u << en) - 1u);
-                unite_glb(par, node, (row0 + st) * W + c - 1);
-            }
-        }
-    }
+    if (tile_left)
+        bitrun_left_links(w, wb[(int64_t)ch * W + c - 1], [&](int a, int st) { unite_glb(par, (row0 + a) * W + c, (row0 + st) * W + c - 1); });
     if ((w & 1u) && ch > 0) {
-        const int node = row0 * W + c;  // the run that starts in row 0 of this word
-        for (int cc = max(c - 1, 0); cc <= min(c + 1, W - 1); ++cc) {
-            const unsigned wu = wb[(int64_t)(ch - 1) * W + cc];
-            if (wu >> 31) unite_glb(par, node, (row0 - 32 + bitrun_start(wu, 31)) * W + cc);
+        const int node = row0 * W + c;
+        const unsigned wu = wb[(int64_t)(ch - 1) * W + c];
+        if (wu >> 31) {
+            if (tile_top) unite_glb(par, node, (row0 - 32 + bitrun_start(wu, 31)) * W + c);
+        } else {
+            // diagonals: made in LDS unless the word above is in another tile row, or the neighbour column in another tile
+            if (c > 0 && (tile_top || col == 0)) {
+                const unsigned wd = wb[(int64_t)(ch - 1) * W + c - 1];
+                if (wd >> 31) unite_glb(par, node, (row0 - 32 + bitrun_start(wd, 31)) * W + c - 1);
+            }
+            if (c + 1 < W && (tile_top || col == BR_TW - 1)) {
+                const unsigned wd = wb[(int64_t)(ch - 1) * W + c + 1];
+                if (wd >> 31) unite_glb(par, node, (row0 - 32 + bitrun_start(wd, 31)) * W + c + 1);
+            }
         }
     }
 }
@@ -767,7 +795,7 @@ int pcseg_dilate_ccl_roots_u8(const uint8_t *in, uint64_t value_bits, int radius
         PCSEG_LAUNCH(set_bits_kernel, g, dim3(256), 0, s, in, (unsigned long long)value_bits, bits, H, W, nch);
     }
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, dil, radius, H, W, nch, (int *)nullptr);
+    PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, dil, radius, H, W, nch);
     PCSEG_CHECK_LAUNCH();
     return ccl_roots<KeyBits, true>(KeyBits{dil, W, nch}, roots, B, H, W, s);
 }
@@ -800,10 +828,12 @@ int pcseg_dilate_ccl_runs_u8(const uint8_t *in, uint64_t value_bits, int radius,
         PCSEG_LAUNCH(set_bits_kernel, g, dim3(256), 0, s, in, (unsigned long long)value_bits, bits, H, W, nch);
     }
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, (unsigned *)dilated_bits, radius, H, W, nch,
-                 (int *)run_parent);
+    PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, (unsigned *)dilated_bits, radius, H, W, nch);
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(bitrun_link_kernel, g, dim3(256), 0, s, (const unsigned *)dilated_bits, (int *)run_parent, H, W, nch);
+    PCSEG_LAUNCH(bitrun_tile_kernel, dim3((W + BR_TW - 1) / BR_TW, (nch + BR_CH - 1) / BR_CH, B), dim3(256), 0, s,
+                 (const unsigned *)dilated_bits, (int *)run_parent, H, W, nch);
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_LAUNCH(bitrun_border_kernel, g, dim3(256), 0, s, (const unsigned *)dilated_bits, (int *)run_parent, H, W, nch);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

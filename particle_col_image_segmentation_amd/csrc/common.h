@@ -138,10 +138,16 @@ __device__ __forceinline__ void unite_glb(int *par, int a, int b)
     }
 }
 
-// ccl.hip, for the fused label + region-table driver in reduce.hip: union-find roots of the equal-valued 8-connected
-// components (unflattened parents in the workspace), raster ranks of the roots as codes at the root pixels of `codes`,
-// counts[b], and the scanned per-block offsets (block = 1024 consecutive pixels)
-int ccl_equal_u8_roots_and_ranks(const uint8_t *in, int *codes, int *counts, int **parent, int **blockoff, int *nblk, int B, int H,
-                                 int W, void *workspace, size_t workspace_bytes, hipStream_t s);
+// ccl.hip, for the fused class-map front end (frontend.hip): where the union-find image and the per-block root counts
+// live in a pcseg_ccl_workspace_bytes workspace, and the passes after the tile pass for equal-valued 8-connected
+// components of a uint8 image (border links, flatten + count, scan, relabel -> raster-order labels)
+struct CclPlan {
+    int *parent;
+    int *blockcount;
+    int nblk;
+};
+int ccl_plan(void *workspace, size_t workspace_bytes, int B, int H, int W, CclPlan *plan, const char *who);
+int ccl_equal_u8_finish(const uint8_t *in, const CclPlan &plan, bool tile_pass_done, int *labels, int *counts, int B, int H, int W,
+                        hipStream_t s);
 
 }  // namespace pcseg

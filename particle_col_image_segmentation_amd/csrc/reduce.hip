@@ -206,19 +206,8 @@ __device__ __forceinline__ void region_commit(const RegionSlots &ls, long long *
 // changes.  No cross-lane traffic at all; loads are int4 / float4 and coalesced along the row.
 constexpr int COL_ROWS = 32;
 
-// DECODE: the labels do not exist yet.  `decode.parent` is the (unflattened) union-find image of the components and
-// `labels` holds, at every ROOT pixel, the rank code the counting pass left there; a lane turns the parents of its four
-// columns into final labels while it walks down (root chase + one table look-up, repeated only when the parent entry
-// changes -- inside a tile all pixels of a component share theirs), WRITES the label image and feeds the same run
-// logic.  The separate relabel pass and its read of the label image disappear.
-struct LabelDecode {
-    const int *parent;    // (B, H, W), -1 = background
-    const int *blockoff;  // (B, nblk) exclusive scan of the per-block root counts
-    int nblk;
-};
-
-template <int NC, bool DECODE>
-__global__ void __launch_bounds__(256) region_reduce_col_kernel(int *labels, LabelDecode decode, const float *__restrict__ planes,
+template <int NC>
+__global__ void __launch_bounds__(256) region_reduce_col_kernel(const int *__restrict__ labels, const float *__restrict__ planes,
                                                                  const uint8_t *__restrict__ cls, unsigned long long sel, int C,
                                                                  int H, int W, int cap, long long *__restrict__ stats,
                                                                  double *__restrict__ sums, int *__restrict__ overflow)
@@ -228,8 +217,7 @@ __global__ void __launch_bounds__(256) region_reduce_col_kernel(int *labels, Lab
     __shared__ double lsum[NC > 0 ? RED_SLOTS : 1][RED_MAXC];
     const int b = blockIdx.z;
     const int64_t n = (int64_t)H * W;
-    int *lab = labels + (int64_t)b * n;
-    const int *par = DECODE ? decode.parent + (int64_t)b * n : nullptr;
+    const int *lab = labels + (int64_t)b * n;
     const float *pl = NC > 0 ? planes + (int64_t)b * C * n : nullptr;
     long long *gst = stats + (int64_t)b * cap * 8;
     double *gsum = NC > 0 ? sums + (int64_t)b * cap * C : nullptr;
@@ -242,7 +230,6 @@ __global__ void __launch_bounds__(256) region_reduce_col_kernel(int *labels, Lab
     }
     __syncthreads();
     const RegionSlots ls{tags, lstat, lsum};
-    int lastp[4] = {-1, -1, -1, -1}, lastl[4] = {0, 0, 0, 0};  // DECODE: parent entry -> label of the pixel above
     const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int r0 = blockIdx.y * COL_ROWS, r1 = min(H, r0 + COL_ROWS);
     if (c < W) {
@@ -264,36 +251,7 @@ __global__ void __launch_bounds__(256) region_reduce_col_kernel(int *labels, Lab
         auto fetch = [&](int r) {
             l4n = make_int4(0, 0, 0, 0);
             if (r < r1) {
-                if (DECODE) {
-                    const int4 p4 = *reinterpret_cast<const int4 *>(par + (int64_t)r * W + c);
-                    const int pv[4] = {p4.x, p4.y, p4.z, p4.w};
-                    int lv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (pv[j] < 0) {
-                            lv[j] = 0;
-                        } else {
-                            if (pv[j] != lastp[j]) {
-                                if (j > 0 && pv[j] == pv[j - 1]) {
-                                    lastl[j] = lv[j - 1];
-                                } else {
-                                    int x = pv[j], q;
-                                    while ((q = par[x]) != x) x = q;
-                                    // rank code (negative) or the final label the root's own lane has written meanwhile:
-                                    // both decode to the same number
-                                    const int code = __hip_atomic_load(lab + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    lastl[j] = code < 0 ? decode.blockoff[b * decode.nblk + x / 1024] - code : code;
-                                }
-                                lastp[j] = pv[j];
-                            }
-                            lv[j] = lastl[j];
-                        }
-                    }
-                    l4n = make_int4(lv[0], lv[1], lv[2], lv[3]);
-                    *reinterpret_cast<int4 *>(lab + (int64_t)r * W + c) = l4n;
-                } else {
-                    l4n = *reinterpret_cast<const int4 *>(lab + (int64_t)r * W + c);
-                }
+                l4n = *reinterpret_cast<const int4 *>(lab + (int64_t)r * W + c);
                 if (NC > 0) {
                     if (sel) {
                         const unsigned cw = *reinterpret_cast<const unsigned *>(cls + (int64_t)b * n + (int64_t)r * W + c);
@@ -429,61 +387,68 @@ __device__ __forceinline__ int block_exclusive_scan256(int v, int *total, int *w
     return base + inc - v;
 }
 
-__global__ void __launch_bounds__(256) merge_groups_kernel(const int *__restrict__ dl, const long long *__restrict__ stats,
-                                                            const int *__restrict__ region_list, const int *__restrict__ n_list,
-                                                            int *__restrict__ group_of, int *__restrict__ n_groups,
-                                                            int *__restrict__ key_ws, int *__restrict__ first_ws,
-                                                            int *__restrict__ gid_ws, int H, int W, int cap, int list_cap,
-                                                            int keys_are_roots, const unsigned *__restrict__ run_bits)
+// keys (tiff_analysis.py:844-848): dilated label at (int(cy), int(cx)); exact with integer floor division.  One thread
+// per list entry over the whole batch: the look-up walks a union-find chain in global memory, which is pure latency --
+// it wants many blocks in flight, not the one block per frame of the grouping kernel below.
+__global__ void __launch_bounds__(256) merge_keys_kernel(const int *__restrict__ dl, const long long *__restrict__ stats,
+                                                          const int *__restrict__ region_list, const int *__restrict__ n_list,
+                                                          int *__restrict__ key_ws, int H, int W, int cap, int list_cap,
+                                                          int keys_are_roots, const unsigned *__restrict__ run_bits)
 {
-    __shared__ int wsum[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     const int R = min(n_list[b], list_cap);
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= R) return;
     const int64_t n = (int64_t)H * W;
     const int *dlab = dl + (int64_t)b * n;
     const long long *st = stats + (int64_t)b * cap * 8;
-    const int *lst = region_list + (int64_t)b * list_cap;
-    int *key = key_ws + (int64_t)b * list_cap;
-    int *first = first_ws + (int64_t)b * (list_cap + 1);
-    int *gid = gid_ws + (int64_t)b * list_cap;
-    int *gof = group_of + (int64_t)b * list_cap;
-    // keys (tiff_analysis.py:844-848): dilated label at (int(cy), int(cx)); exact with integer floor division
-    for (int k = threadIdx.x; k < R; k += 256) {
-        int key_k = 0;
-        int r = lst[k];
-        if (r >= 0 && r < cap) {
-            long long a = st[(int64_t)r * 8 + 0];
-            if (a > 0) {
-                long long y = st[(int64_t)r * 8 + 1] / a, x = st[(int64_t)r * 8 + 2] / a;
-                if (y >= 0 && y < H && x >= 0 && x < W) {
-                    if (run_bits) {
-                        // components by vertical runs (pcseg_dilate_ccl_runs_u8): the node of a set pixel is the top
-                        // pixel of its run inside the 32-row word; only those entries of the parent array exist
-                        const int nch = (H + 31) / 32;
-                        const unsigned word = run_bits[((int64_t)b * nch + (int)(y >> 5)) * W + x];
-                        const int j = (int)(y & 31);
-                        if ((word >> j) & 1u) {
-                            const unsigned below = ~word & ((1u << j) - 1u);
-                            const int st = below ? 32 - __clz(below) : 0;
-                            key_k = (int)((y - j + st) * W + x);
-                            int q;
-                            while ((q = dlab[key_k]) != key_k) key_k = q;
-                            key_k += 1;
-                        }
-                    } else {
-                        key_k = dlab[y * W + x];
-                        if (keys_are_roots) {  // parent image of a union-find (-1 = background): walk to the root
-                            int q;
-                            while (key_k >= 0 && (q = dlab[key_k]) != key_k) key_k = q;
-                            key_k += 1;
-                        }
+    int key_k = 0;
+    const int r = region_list[(int64_t)b * list_cap + k];
+    if (r >= 0 && r < cap) {
+        const long long a = st[(int64_t)r * 8 + 0];
+        if (a > 0) {
+            const long long y = st[(int64_t)r * 8 + 1] / a, x = st[(int64_t)r * 8 + 2] / a;
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                if (run_bits) {
+                    // components by vertical runs (pcseg_dilate_ccl_runs_u8): the node of a set pixel is the top
+                    // pixel of its run inside the 32-row word; only those entries of the parent array exist
+                    const int nch = (H + 31) / 32;
+                    const unsigned word = run_bits[((int64_t)b * nch + (int)(y >> 5)) * W + x];
+                    const int j = (int)(y & 31);
+                    if ((word >> j) & 1u) {
+                        const unsigned below = ~word & ((1u << j) - 1u);
+                        const int start = below ? 32 - __clz(below) : 0;
+                        key_k = (int)((y - j + start) * W + x);
+                        int q;
+                        while ((q = dlab[key_k]) != key_k) key_k = q;
+                        key_k += 1;
+                    }
+                } else {
+                    key_k = dlab[y * W + x];
+                    if (keys_are_roots) {  // parent image of a union-find (-1 = background): walk to the root
+                        int q;
+                        while (key_k >= 0 && (q = dlab[key_k]) != key_k) key_k = q;
+                        key_k += 1;
                     }
                 }
             }
         }
-        key[k] = key_k;
     }
-    __syncthreads();
+    key_ws[(int64_t)b * list_cap + k] = key_k;
+}
+
+// grouping of one frame's list by key (one block per frame; keys from merge_keys_kernel)
+__global__ void __launch_bounds__(256) merge_groups_kernel(const int *__restrict__ n_list, int *__restrict__ group_of,
+                                                            int *__restrict__ n_groups, int *__restrict__ key_ws,
+                                                            int *__restrict__ first_ws, int *__restrict__ gid_ws, int list_cap)
+{
+    __shared__ int wsum[4];
+    const int b = blockIdx.x;
+    const int R = min(n_list[b], list_cap);
+    int *key = key_ws + (int64_t)b * list_cap;
+    int *first = first_ws + (int64_t)b * (list_cap + 1);
+    int *gid = gid_ws + (int64_t)b * list_cap;
+    int *gof = group_of + (int64_t)b * list_cap;
     // dilated labels are arbitrary in 1..K (K may exceed the list length): remap through the list itself --
     // first[] is indexed by the LIST POSITION of the first entry seen with that key, found by a tiny hash on key
     // (open addressing over list_cap + 1 slots, keys stored in gid as scratch)
@@ -737,13 +702,13 @@ int pcseg_region_reduce_sel(const int32_t *labels, const int32_t *counts, const 
                      (!sel || ((uintptr_t)cls % 4) == 0);
     const dim3 cgrid((W / 4 + 255) / 256, (H + COL_ROWS - 1) / COL_ROWS, B);
     if (vec && planes && C <= 5)
-        PCSEG_LAUNCH((region_reduce_col_kernel<5, false>), cgrid, dim3(256), 0, s, (int *)labels, LabelDecode{nullptr, nullptr, 0}, planes, cls, sel, C, H, W, cap, (long long *)stats, sums,
+        PCSEG_LAUNCH(region_reduce_col_kernel<5>, cgrid, dim3(256), 0, s, labels, planes, cls, sel, C, H, W, cap, (long long *)stats, sums,
                      overflow);
     else if (vec && planes)
-        PCSEG_LAUNCH((region_reduce_col_kernel<8, false>), cgrid, dim3(256), 0, s, (int *)labels, LabelDecode{nullptr, nullptr, 0}, planes, cls, sel, C, H, W, cap, (long long *)stats, sums,
+        PCSEG_LAUNCH(region_reduce_col_kernel<8>, cgrid, dim3(256), 0, s, labels, planes, cls, sel, C, H, W, cap, (long long *)stats, sums,
                      overflow);
     else if (vec)
-        PCSEG_LAUNCH((region_reduce_col_kernel<0, false>), cgrid, dim3(256), 0, s, (int *)labels, LabelDecode{nullptr, nullptr, 0}, planes, cls, sel, C, H, W, cap, (long long *)stats, sums,
+        PCSEG_LAUNCH(region_reduce_col_kernel<0>, cgrid, dim3(256), 0, s, labels, planes, cls, sel, C, H, W, cap, (long long *)stats, sums,
                      overflow);
     else if (planes)
         PCSEG_LAUNCH(region_reduce_kernel<true>, grid, dim3(256), 0, s, labels, planes, cls, sel, C, H, W, cap, (long long *)stats,
@@ -757,50 +722,6 @@ int pcseg_region_reduce_sel(const int32_t *labels, const int32_t *counts, const 
                            (int64_t)H * W);
         PCSEG_CHECK_LAUNCH();
     }
-    return PCSEG_OK;
-}
-
-size_t pcseg_label_regions_workspace_bytes(int B, int H, int W) { return pcseg_ccl_workspace_bytes(B, H, W); }
-
-int pcseg_label_regions_u8(const uint8_t *in, uint64_t sum_class_bits, const float *planes, int C, int32_t *labels,
-                           int32_t *counts, int B, int H, int W, int cap, int64_t *stats, uint8_t *cls_out, double *sums,
-                           int32_t *overflow, void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
-{
-    PCSEG_REQUIRE(in && labels && counts && stats && cls_out && workspace && cap >= 1 && check_shape(B, H, W), "bad arguments");
-    PCSEG_REQUIRE((!planes && !sums) || (planes && sums && C >= 1 && C <= RED_MAXC), "planes/sums/C mismatch (C <= 8)");
-    PCSEG_REQUIRE(sum_class_bits == 0 || planes, "a class selection needs planes");
-    hipStream_t s = (hipStream_t)stream;
-    const bool fused = (W % 4) == 0 && ((uintptr_t)labels % 16) == 0 && (!planes || ((uintptr_t)planes % 16) == 0) &&
-                       ((uintptr_t)in % 4) == 0 && ((uintptr_t)workspace % 16) == 0;
-    if (!fused) {  // odd widths: the two-step path (label image first, generic row kernel)
-        int rc = pcseg_ccl8_equal_u8(in, labels, counts, B, H, W, workspace, workspace_bytes, stream);
-        if (rc) return rc;
-        return pcseg_region_reduce_sel(labels, counts, in, sum_class_bits, planes, C, B, H, W, cap, stats, cls_out, sums, overflow,
-                                       stream);
-    }
-    int *parent = nullptr, *blockoff = nullptr;
-    int nblk = 0;
-    int rc = ccl_equal_u8_roots_and_ranks(in, labels, counts, &parent, &blockoff, &nblk, B, H, W, workspace, workspace_bytes, s);
-    if (rc) return rc;
-    if (overflow) PCSEG_CHECK_HIP(hipMemsetAsync(overflow, 0, sizeof(int32_t) * B, s));
-    dim3 gi((cap + 255) / 256, B);
-    PCSEG_LAUNCH(region_init_kernel, gi, dim3(256), 0, s, (long long *)stats, sums, (const int *)counts, cap, C, H, W);
-    PCSEG_CHECK_LAUNCH();
-    const dim3 cgrid((W / 4 + 255) / 256, (H + COL_ROWS - 1) / COL_ROWS, B);
-    const LabelDecode dec{parent, blockoff, nblk};
-    const unsigned long long sel = sum_class_bits;
-    if (planes && C <= 5)
-        PCSEG_LAUNCH((region_reduce_col_kernel<5, true>), cgrid, dim3(256), 0, s, (int *)labels, dec, planes, in, sel, C, H, W, cap,
-                     (long long *)stats, sums, overflow);
-    else if (planes)
-        PCSEG_LAUNCH((region_reduce_col_kernel<8, true>), cgrid, dim3(256), 0, s, (int *)labels, dec, planes, in, sel, C, H, W, cap,
-                     (long long *)stats, sums, overflow);
-    else
-        PCSEG_LAUNCH((region_reduce_col_kernel<0, true>), cgrid, dim3(256), 0, s, (int *)labels, dec, planes, in, sel, C, H, W, cap,
-                     (long long *)stats, sums, overflow);
-    PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(region_class_kernel, gi, dim3(256), 0, s, (const long long *)stats, in, (const int *)counts, cls_out, cap, (int64_t)H * W);
-    PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }
 
@@ -831,9 +752,10 @@ int pcseg_merge_groups(const int32_t *dilated_labels, int keys_are_roots, const 
         set_error("merge_groups: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
     }
-    PCSEG_LAUNCH(merge_groups_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dilated_labels,
-                       (const long long *)stats, region_list, n_list, group_of, n_groups, key, first, gid, H, W, cap, list_cap,
-                       keys_are_roots, (const unsigned *)nullptr);
+    PCSEG_LAUNCH(merge_keys_kernel, dim3((list_cap + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dilated_labels,
+                 (const long long *)stats, region_list, n_list, key, H, W, cap, list_cap, keys_are_roots, (const unsigned *)nullptr);
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_LAUNCH(merge_groups_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, n_list, group_of, n_groups, key, first, gid, list_cap);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }
@@ -853,8 +775,10 @@ int pcseg_merge_groups_runs(const uint32_t *dilated_bits, const int32_t *run_par
         set_error("merge_groups_runs: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
     }
-    PCSEG_LAUNCH(merge_groups_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, run_parent, (const long long *)stats, region_list,
-                 n_list, group_of, n_groups, key, first, gid, H, W, cap, list_cap, 1, (const unsigned *)dilated_bits);
+    PCSEG_LAUNCH(merge_keys_kernel, dim3((list_cap + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, run_parent,
+                 (const long long *)stats, region_list, n_list, key, H, W, cap, list_cap, 1, (const unsigned *)dilated_bits);
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_LAUNCH(merge_groups_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, n_list, group_of, n_groups, key, first, gid, list_cap);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

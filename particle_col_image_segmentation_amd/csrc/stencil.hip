@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "common.h"
+#include "tile_ops.h"
 
 namespace pcseg {
 
@@ -101,16 +102,6 @@ __global__ void __launch_bounds__(256) argmax_kernel(const float *__restrict__ s
 // bytes is built bit by bit: med = max t with #(v >= t) >= 13; the number of
 // bit rounds is block-uniform (from the tile maximum), so a class map with
 // values <= 7 costs 3 rounds.
-constexpr int MED_TW = 64, MED_TH = 32, MED_LW = 72 /* 64 + 4 rounded to 8 */, MED_LH = MED_TH + 4;
-
-__device__ __forceinline__ int reflect_idx(int i, int n)
-{
-    int p = 2 * n;
-    i %= p;
-    if (i < 0) i += p;
-    return i < n ? i : p - 1 - i;
-}
-
 __global__ void __launch_bounds__(256) median5_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int H, int W)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[MED_LH * MED_LW];
@@ -147,26 +138,8 @@ __global__ void __launch_bounds__(256) median5_kernel(const uint8_t *__restrict_
             const int lr = s / (MED_TW / 4), lc = (s % (MED_TW / 4)) * 4;
             const int r = r0 + lr;
             if (r >= H || c0 + lc >= W) continue;
-            uint32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int dr = 0; dr < 5; ++dr) {
-                const uint4 *row = reinterpret_cast<const uint4 *>(hot + (lr + dr) * MED_LW + lc);
-                const uint4 a = row[0], bq = row[1];
-                col[0] += a.x; col[1] += a.y; col[2] += a.z; col[3] += a.w;
-                col[4] += bq.x; col[5] += bq.y; col[6] += bq.z; col[7] += bq.w;
-            }
             uint32_t med[4];
-            uint32_t w = col[0] + col[1] + col[2] + col[3] + col[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j > 0) w += col[j + 4] - col[j - 1];
-                // cumulative counts of the values <= k in field k (no carries: every prefix is <= 25)
-                const uint32_t cum = w * 0x02108421u;
-                uint32_t m = 0;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) m += ((cum >> (5 * k)) & 31u) < 13u ? 1u : 0u;
-                med[j] = m;
-            }
+            median5_hot_strip(hot, lr, lc, med);
             const int c = c0 + lc;
             if (c + 3 < W && (W & 3) == 0) {
                 *reinterpret_cast<uint32_t *>(dst + (int64_t)r * W + c) = med[0] | (med[1] << 8) | (med[2] << 16) | (med[3] << 24);

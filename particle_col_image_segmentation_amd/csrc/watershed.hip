@@ -21,6 +21,7 @@
 //   * frames that fail the check (equal-valued bottlenecks or seeds between two
 //     basins -- ubiquitous in quantised probability maps) are recomputed by an
 //     exact emulation of the reference's binary heap, one wave per frame.
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <type_traits>
@@ -327,12 +328,21 @@ __global__ void __launch_bounds__(256) ws_relax_tail_kernel(WsInputs in, unsigne
 
 
 // kernels of the second level are launched over the flagged frames only: grid index -> frame id through a list
-// (the list and its length stay on the device: the grid covers the worst case, blocks past the length get -1 and leave)
-__device__ __forceinline__ int ws_frame(const int *frame_list, int grid_index)
+// The list and its length (frame_list[-1]) stay on the device.  A launch over a list only spans WS_LIST_SPAN entries in
+// the frame dimension of its grid and every block walks the list with that stride: a launch that finds the list
+// empty (the usual case on tie-free data) retires few blocks, a batch in which every frame is listed loops.
+constexpr int WS_LIST_SPAN = 8;
+template <typename Body>
+__device__ __forceinline__ void ws_for_frames(const int *frame_list, int grid_index, int grid_size, Body &&body)
 {
-    if (!frame_list) return grid_index;
-    return grid_index < frame_list[-1] ? frame_list[grid_index] : -1;
+    if (!frame_list) {
+        body(grid_index);
+        return;
+    }
+    const int n = frame_list[-1];
+    for (int gi = grid_index; gi < n; gi += grid_size) body(frame_list[gi]);
 }
+static inline int ws_frame_span(const int *frame_list, int B) { return frame_list ? (B < WS_LIST_SPAN ? B : WS_LIST_SPAN) : B; }
 
 // stage-2 work is restricted to the 64x64 tiles that hold a pixel of an unresolved component (active == nullptr: all)
 __device__ __forceinline__ bool ws_active(const uint8_t *active, int b, int r, int c, int tilesX, int tilesY)
@@ -400,15 +410,12 @@ __device__ __forceinline__ void vunite_glb(int *par, int p, int q)
 }
 
 template <typename KeyT>
-__global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__ frame_list, const KeyT *__restrict__ K, const int *__restrict__ F,
-                                                          const uint8_t *__restrict__ active, int *__restrict__ parent,
-                                                          uint8_t *__restrict__ minmask, int H, int W, int tilesX, int tilesY)
+__device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM, const int b, const KeyT *__restrict__ K,
+                                                 const int *__restrict__ F, const uint8_t *__restrict__ active,
+                                                 int *__restrict__ parent, uint8_t *__restrict__ minmask, int H, int W, int tilesX,
+                                                 int tilesY)
 {
-    __shared__ KeyT sK[UF_SH * UF_SW];
-    __shared__ int par[UF_TH * UF_TW];
     const KeyT KINF = ~(KeyT)0;
-    const int b = ws_frame(frame_list, blockIdx.z);
-    if (b < 0) return;
     const int r0 = blockIdx.y * UF_TH, c0 = blockIdx.x * UF_TW;
     if (!ws_active(active, b, r0, c0, tilesX, tilesY)) return;  // UF tiles (64x32) nest inside the 64x64 tiles
     const int64_t fbase = (int64_t)b * H * W;
@@ -420,7 +427,6 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__
     // (1) per pixel: own virtual index and which neighbours hold the minimum neighbour key (bit0 up, 1 left, 2 right,
     // 3 down; 0 for seeds / unreachable).  The masks also go to global memory for the border pass, which then needs
     // two bytes per cross-tile pair instead of ten keys.
-    __shared__ uint8_t sM[UF_LNS];
     int self[UF_LNS / 256];  // -1: unreachable / outside
 #pragma unroll
     for (int k = 0; k < UF_LNS / 256; ++k) {
@@ -496,6 +502,27 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__
     }
 }
 
+// LIST = false: every frame (first level), one frame per grid slice, straight-line code (32 VGPRs, 8 waves / SIMD; the
+// looping variant needs 80); LIST = true: the listed frames, see ws_for_frames
+template <typename KeyT, bool LIST>
+__global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__ frame_list, const KeyT *__restrict__ K, const int *__restrict__ F,
+                                                          const uint8_t *__restrict__ active, int *__restrict__ parent,
+                                                          uint8_t *__restrict__ minmask, int H, int W, int tilesX, int tilesY)
+{
+    __shared__ KeyT sK[UF_SH * UF_SW];
+    __shared__ int par[UF_TH * UF_TW];
+    __shared__ uint8_t sM[UF_LNS];
+    if constexpr (!LIST) {
+        ws_uf_tile_frame<KeyT>(sK, par, sM, blockIdx.z, K, F, active, parent, minmask, H, W, tilesX, tilesY);
+    } else {
+        const int n = frame_list[-1];
+        for (int gi = blockIdx.z; gi < n; gi += gridDim.z) {
+            ws_uf_tile_frame<KeyT>(sK, par, sM, frame_list[gi], K, F, active, parent, minmask, H, W, tilesX, tilesY);
+            __syncthreads();  // the next listed frame reuses the tile arrays
+        }
+    }
+}
+
 // cross-tile links from the neighbour masks the tile pass left behind
 __global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict__ frame_list, const uint8_t *__restrict__ minmask, const uint8_t *__restrict__ active,
                                                             int *__restrict__ parent, int H, int W, int tilesX, int tilesY)
@@ -515,8 +542,7 @@ __global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict
         if ((r % UF_TH) == 0 && r > 0) return;  // handled with its row above
         c = (i / H + 1) * UF_TW;
     }
-    const int b = ws_frame(frame_list, blockIdx.y);
-    if (b < 0) return;
+    ws_for_frames(frame_list, blockIdx.y, gridDim.y, [&](const int b) {
     if (!ws_active(active, b, r, c, tilesX, tilesY)) return;
     const bool top = (r % UF_TH) == 0 && r > 0;
     const bool left = (c % UF_TW) == 0 && c > 0;
@@ -551,6 +577,7 @@ __global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict
             if (!implied) vunite_glb(par, p, p - 1);
         }
     }
+    });
 }
 
 // Labels from the roots.  A component that holds two differently labelled pixels cannot be resolved at this level:
@@ -569,9 +596,8 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
                                                            int *__restrict__ tie_flags, uint8_t *__restrict__ mark_active, int64_t n,
                                                            int W, int tilesX, int tilesY)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = ws_frame(frame_list, blockIdx.y);
-    if (b < 0) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    ws_for_frames(frame_list, blockIdx.y, gridDim.y, [&](const int b) {
     const int r = (int)(i / W), c = (int)(i % W);
     if (i >= n || !ws_active(active, b, r, c, tilesX, tilesY)) return;
     const int64_t fbase = (int64_t)b * n, g = fbase + i;
@@ -601,6 +627,7 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
         bad[groot] = 1;
         if (tie_flags[b] == 0) tie_flags[b] = 1;
     }
+    });
 }
 
 // UF_OPTIMISTIC over whole frames with W % 4 == 0: four pixels per lane (16-byte parent / label accesses; neighbours
@@ -689,8 +716,7 @@ __global__ void __launch_bounds__(256) ws_k2_init_kernel(const int *__restrict__
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (r >= H || c >= W) return;
-    const int b = ws_frame(frame_list, blockIdx.z);
-    if (b < 0) return;
+    ws_for_frames(frame_list, blockIdx.z, gridDim.z, [&](const int b) {
     if (!ws_active(active, b, r, c, tilesX, tilesY)) return;
     const int64_t i = (int64_t)b * H * W + (int64_t)r * W + c;
     const unsigned l = L[i];
@@ -705,6 +731,7 @@ __global__ void __launch_bounds__(256) ws_k2_init_kernel(const int *__restrict__
         }
     }
     K2[i] = k;
+    });
 }
 
 struct WsK2Lds {
@@ -769,9 +796,10 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict_
                                                            int H, int W, int tilesX, int tilesY)
 {
     __shared__ WsK2Lds lds;
-    const int b = ws_frame(frame_list, blockIdx.z);
-    if (b < 0) return;
-    ws_k2_relax_tile(lds, val, L, K2, active, dirty_in, dirty_out, H, W, tilesX, tilesY, blockIdx.x, blockIdx.y, b);
+    ws_for_frames(frame_list, blockIdx.z, gridDim.z, [&](const int b) {
+        ws_k2_relax_tile(lds, val, L, K2, active, dirty_in, dirty_out, H, W, tilesX, tilesY, blockIdx.x, blockIdx.y, b);
+        __syncthreads();  // the next listed frame reuses the tile arrays
+    });
 }
 
 // the rest of the second-level fixed point after its grid rounds, one block per flagged frame (see ws_relax_tail_kernel)
@@ -782,8 +810,7 @@ __global__ void __launch_bounds__(256) ws_k2_relax_tail_kernel(const int *__rest
                                                                 int tilesX, int tilesY, int max_rounds)
 {
     __shared__ WsK2Lds lds;
-    const int b = ws_frame(frame_list, blockIdx.x);
-    if (b < 0) return;
+    ws_for_frames(frame_list, blockIdx.x, gridDim.x, [&](const int b) {
     uint8_t *din = dirtyA, *dout = dirtyB;
     const int ntiles = tilesX * tilesY;
     for (int round = 0;; ++round) {
@@ -802,6 +829,7 @@ __global__ void __launch_bounds__(256) ws_k2_relax_tail_kernel(const int *__rest
         }
         uint8_t *tmp = din; din = dout; dout = tmp;
     }
+    });
 }
 
 // K64 = (L << 32) | K2 inside the active tiles; every other pixel of
@@ -812,9 +840,8 @@ __global__ void __launch_bounds__(256) ws_pack_kernel(const int *__restrict__ fr
                                                        unsigned long long *__restrict__ K64, int64_t n, int W, int tilesX,
                                                        int tilesY)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = ws_frame(frame_list, blockIdx.y);
-    if (b < 0) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    ws_for_frames(frame_list, blockIdx.y, gridDim.y, [&](const int b) {
     if (i >= n || frame_flags[b] == 0) return;
     const int64_t g = (int64_t)b * n + i;
     if (ws_active(active, b, (int)(i / W), (int)(i % W), tilesX, tilesY)) {
@@ -822,6 +849,7 @@ __global__ void __launch_bounds__(256) ws_pack_kernel(const int *__restrict__ fr
     } else {
         K64[g] = ((unsigned long long)L[g] << 32) | 0xFFFFFFFFull;
     }
+    });
 }
 
 // verification builds of the second level run on whole flagged frames: every tile of such a frame becomes active and
@@ -830,15 +858,15 @@ __global__ void __launch_bounds__(256) ws_activate_frames_kernel(const int *__re
                                                                   const int *__restrict__ markers, const uint8_t *__restrict__ mask,
                                                                   int *__restrict__ out, int64_t n, int W, int tilesX, int tilesY)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = ws_frame(frame_list, blockIdx.y);
-    if (b < 0) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    ws_for_frames(frame_list, blockIdx.y, gridDim.y, [&](const int b) {
     if (i >= n || frame_flags[b] == 0) return;
     active[((int64_t)b * tilesY + (int)(i / W) / WS_T) * tilesX + (int)(i % W) / WS_T] = 1;
     out[(int64_t)b * n + i] = mask[(int64_t)b * n + i] ? markers[(int64_t)b * n + i] : 0;
+    });
 }
 
-// flagged frames, in order, as a device-side list; its length sits in front of it (frame_list[-1], see ws_frame)
+// flagged frames, in order, as a device-side list; its length sits in front of it (frame_list[-1], see ws_for_frames)
 __global__ void ws_list_flagged_kernel(const int *__restrict__ flags, int B, int *__restrict__ frame_list)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -877,28 +905,34 @@ __global__ void ws_set_flags_kernel(int *flags, int B, int v)
 //   * sift-up: lane s loads ancestor c >> s, one ballot gives the number of levels the new key climbs;
 //   * the four neighbours of the popped pixel are examined by four lanes while the sift-down is in flight.
 // Comparisons and moves are those of the sequential heappush / heappop, so the pop order is identical.
-constexpr int EX_LDS = 8192;  // 2^13: levels 0..12 (96 KB of the CU's 160 KB)
+// Heap slots kept in LDS: 2^13 (levels 0..12, 96 KB: one frame per CU, two of the three sift-down windows of a 1024^2
+// frame stay in LDS) when the call has at most one frame per CU, or 2^7 (levels 0..6, 1.5 KB: only the first window) for
+// larger calls, where throughput comes from the number of frames in flight -- the flood of a frame is sequential by
+// definition, so a batch of N frames uses N waves whatever else is done, and 16+ of them fit a CU once the LDS share
+// is small.  Both sizes keep every six-level window entirely in LDS or entirely in the workspace.
+constexpr int EX_LDS_BIG = 8192, EX_LDS_SMALL = 128;
 
 struct ExactHeap {
     unsigned long long *lk;  // LDS keys   (slot d at lk[d], slot 0 unused)
     unsigned *lx;            // LDS pixel indices
     unsigned long long *gk;  // workspace keys (slot d at gk[d])
     unsigned *gx;
+    int lds;  // slots below this index live in LDS
     int items;
     unsigned long long tail_key;  // content of slot `items` (the entry the next heappop re-inserts), kept in registers:
     unsigned tail_idx;            // known after a push, fetched ahead of time at the end of a pop
 
     __device__ __forceinline__ unsigned long long key_at(int d) const
     {
-        return d < EX_LDS ? lk[d] : gk[d];
+        return d < lds ? lk[d] : gk[d];
     }
     __device__ __forceinline__ unsigned idx_at(int d) const
     {
-        return d < EX_LDS ? lx[d] : gx[d];
+        return d < lds ? lx[d] : gx[d];
     }
     __device__ __forceinline__ void put(int d, unsigned long long k, unsigned x) const
     {
-        if (d < EX_LDS) {
+        if (d < lds) {
             lk[d] = k;
             lx[d] = x;
         } else {
@@ -994,7 +1028,7 @@ __device__ __forceinline__ void ex_pop(ExactHeap &h)
         const long long d = t >= 1 ? ex_slot(j, t) : (long long)h.items + 1;
         unsigned long long lkey, rkey;
         unsigned lidx, ridx;
-        if (j < EX_LDS / 64) ex_children<true>(h, d, lkey, rkey, lidx, ridx);
+        if (j < h.lds / 64) ex_children<true>(h, d, lkey, rkey, lidx, ridx);
         else ex_children<false>(h, d, lkey, rkey, lidx, ridx);
         // which child would move into this node if the key being placed arrived here
         int next = 0;
@@ -1024,10 +1058,22 @@ __device__ __forceinline__ void ex_pop(ExactHeap &h)
     h.tail_idx = h.idx_at(h.items);
 }
 
-__global__ void __launch_bounds__(256) ws_exact_kernel(const unsigned *__restrict__ val, const int *__restrict__ markers,
-                                                        const uint8_t *__restrict__ mask, int *__restrict__ out,
-                                                        const int *__restrict__ flags, unsigned long long *__restrict__ heap_key,
-                                                        unsigned *__restrict__ heap_idx, int H, int W)
+// labels of the flagged frames back to their seeds (wide, one pass) before the one-wave floods start
+__global__ void __launch_bounds__(256) ws_exact_init_kernel(const int *__restrict__ markers, const uint8_t *__restrict__ mask,
+                                                             int *__restrict__ out, const int *__restrict__ flags, int64_t n)
+{
+    const int b = blockIdx.y;
+    if (flags[b] == 0) return;
+    const int64_t base = (int64_t)b * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[base + i] = mask[base + i] ? markers[base + i] : 0;
+}
+
+template <int EX_LDS>
+__global__ void __launch_bounds__(64) ws_exact_kernel(const unsigned *__restrict__ val, const int *__restrict__ markers,
+                                                       const uint8_t *__restrict__ mask, int *__restrict__ out,
+                                                       const int *__restrict__ flags, unsigned long long *__restrict__ heap_key,
+                                                       unsigned *__restrict__ heap_idx, int H, int W)
 {
     __shared__ __attribute__((aligned(16))) unsigned long long lds_key[EX_LDS];
     __shared__ __attribute__((aligned(16))) unsigned lds_idx[EX_LDS];
@@ -1035,16 +1081,12 @@ __global__ void __launch_bounds__(256) ws_exact_kernel(const unsigned *__restric
     if (flags[b] == 0) return;
     const int64_t n = (int64_t)H * W;
     const unsigned *v = val + (int64_t)b * n;
-    const int *mk = markers + (int64_t)b * n;
     const uint8_t *ms = mask + (int64_t)b * n;
     int *o = out + (int64_t)b * n;
-    for (int64_t i = threadIdx.x; i < n; i += 256) o[i] = ms[i] ? mk[i] : 0;
-    __syncthreads();
-    if (threadIdx.x >= WAVE) return;
     const int t = threadIdx.x;
     // slot d (1-based) of the heap is element d - 1 of the sequential heap.  Slots >= EX_LDS live in the workspace, which
     // holds n elements per frame: slot d -> element d - 1, so that slot n (every pixel is pushed at most once) still fits
-    ExactHeap h{lds_key, lds_idx, heap_key + (int64_t)b * n - 1, heap_idx + (int64_t)b * n - 1, 0, 0ull, 0u};
+    ExactHeap h{lds_key, lds_idx, heap_key + (int64_t)b * n - 1, heap_idx + (int64_t)b * n - 1, EX_LDS, 0, 0ull, 0u};
     for (int64_t base = 0; base < n; base += WAVE) {
         const int64_t i = base + t;
         const int seed = i < n ? o[i] : 0;
@@ -1215,17 +1257,23 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                          tilings[0], tilings[1], WS_GRID_ROUNDS, max_rounds);
             PCSEG_CHECK_LAUNCH();
         }
-        const dim3 ugrid((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B);
-        const dim3 lgrid((unsigned)(((size_t)H * W + 255) / 256), B);
+        const dim3 ugrid_full((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B);
+        const dim3 lgrid_full((unsigned)(((size_t)H * W + 255) / 256), B);
         const int64_t npx = (int64_t)H * W;
         const int64_t border_px = (int64_t)((H - 1) / UF_TH) * W + (int64_t)((W - 1) / UF_TW) * H;
-        const dim3 bgrid((unsigned)((border_px + 255) / 256), B);
+        const dim3 bgrid_full((unsigned)((border_px + 255) / 256), B);
         // label assignment = union-find over "minimum-key neighbour" links.  A component holding two marker ids flags
         // its frame, stays unlabelled and (first level) marks its tiles active for the next level.
         auto assign_labels = [&](auto *keys, const int *flist, const uint8_t *act, int *out_flags, bool first_level) -> int {
             using KeyT = std::remove_const_t<std::remove_pointer_t<decltype(keys)>>;
-            PCSEG_LAUNCH(ws_uf_tile_kernel<KeyT>, ugrid, dim3(256), 0, s, flist, (const KeyT *)keys, (const int *)out, act,
-                         uf_parent, uf_mask, H, W, tilesX, tilesY);
+            const int span = ws_frame_span(flist, B);  // frame dimension of the grids (see ws_for_frames)
+            const dim3 ugrid(ugrid_full.x, ugrid_full.y, span), bgrid(bgrid_full.x, span), lgrid(lgrid_full.x, span);
+            if (flist)
+                PCSEG_LAUNCH((ws_uf_tile_kernel<KeyT, true>), ugrid, dim3(256), 0, s, flist, (const KeyT *)keys, (const int *)out, act,
+                             uf_parent, uf_mask, H, W, tilesX, tilesY);
+            else
+                PCSEG_LAUNCH((ws_uf_tile_kernel<KeyT, false>), ugrid, dim3(256), 0, s, flist, (const KeyT *)keys, (const int *)out, act,
+                             uf_parent, uf_mask, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
             if (border_px > 0) {
                 PCSEG_LAUNCH(ws_uf_border_kernel, bgrid, dim3(256), 0, s, flist, (const uint8_t *)uf_mask, act, uf_parent, H, W,
@@ -1269,7 +1317,8 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         {
             unsigned *K2 = heap_idx;
             unsigned long long *K64 = heap_key;
-            const dim3 tgrid(tilesX, tilesY, B);
+            const int span = ws_frame_span(frame_list, B);
+            const dim3 tgrid(tilesX, tilesY, span), lgrid(lgrid_full.x, span), pgrid2(pgrid.x, pgrid.y, span);
             // the components that hold two marker ids go back to their seeds; their tiles are the second level's work
             PCSEG_LAUNCH(ws_uf_label_kernel<UF_REPAIR>, lgrid, dim3(256), 0, s, (const int *)frame_list, (const int *)uf_parent, out,
                          (const uint8_t *)nullptr, uf_bad1, markers, mask, flags, active, npx, W, tilesX, tilesY);
@@ -1283,7 +1332,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             }
             // the fixed-point loop below reuses dirtyB: keep the active set in its own buffer
             PCSEG_CHECK_HIP(hipMemcpyAsync(active_tiles, active, ntiles, hipMemcpyDeviceToDevice, s));
-            PCSEG_LAUNCH(ws_k2_init_kernel, pgrid, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
+            PCSEG_LAUNCH(ws_k2_init_kernel, pgrid2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
                          (const unsigned *)L, markers, mask, (const uint8_t *)active_tiles, K2, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
             // marks of the first round = the active tiles; the other buffer (it held the active set) starts empty
@@ -1313,7 +1362,17 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     }
     if (tie_flags) PCSEG_CHECK_HIP(hipMemcpyAsync(tie_flags, flags2, sizeof(int) * B, hipMemcpyDeviceToDevice, s));
     if (mode != 2) {
-        PCSEG_LAUNCH(ws_exact_kernel, dim3(B), dim3(256), 0, s, val, markers, mask, out, flags2, heap_key, heap_idx, H, W);
+        const int64_t npx = (int64_t)H * W;
+        PCSEG_LAUNCH(ws_exact_init_kernel, dim3((unsigned)std::min<int64_t>((npx + 1023) / 1024, 64), B), dim3(256), 0, s, markers, mask,
+                     out, (const int *)flags2, npx);
+        PCSEG_CHECK_LAUNCH();
+        int ncu = 256;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (B <= ncu)
+            PCSEG_LAUNCH(ws_exact_kernel<EX_LDS_BIG>, dim3(B), dim3(64), 0, s, val, markers, mask, out, flags2, heap_key, heap_idx, H, W);
+        else
+            PCSEG_LAUNCH(ws_exact_kernel<EX_LDS_SMALL>, dim3(B), dim3(64), 0, s, val, markers, mask, out, flags2, heap_key, heap_idx, H, W);
         PCSEG_CHECK_LAUNCH();
     }
     if (unsigned long long *dev_tiles = ws_dev_tiles()) {

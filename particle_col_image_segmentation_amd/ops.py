@@ -56,6 +56,23 @@ def median5(x):
     return out
 
 
+def classmap_label(stack):
+    """class map (argmax + 1) -> median_filter(size=5) -> label (tiff_analysis.py:639-643, 743) as one fused front end:
+    returns (denoised uint8 (B,H,W), labels int32 (B,H,W), counts int32 (B,))."""
+    stack = _req(stack, torch.float32, 4)
+    B, C, H, W = stack.shape
+    dev = stack.device
+    z = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    labels = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    nbytes = lib.pcseg_classmap_label_workspace_bytes(B, H, W)
+    ws = _ws(nbytes, dev)
+    _lib.check(lib.pcseg_classmap_label_f32(_ptr(stack), C, _ptr(z), _ptr(labels), _ptr(counts), B, H, W, _ptr(ws), nbytes, _stream()),
+               "classmap_label")
+    return z, labels, counts
+
+
 def _ccl(fn_name, x):
     x = _req(x, torch.uint8, 3)
     B, H, W = x.shape
@@ -132,35 +149,6 @@ def region_reduce(labels, counts=None, cls=None, planes=None, cap=None, sum_clas
                                            cap, _ptr(stats), _ptr(cls_out), _ptr(sums), _ptr(overflow), _stream()),
                "region_reduce")
     return stats, cls_out, sums, overflow
-
-
-def label_regions(z, planes=None, cap=None, sum_classes=0):
-    """label(z) and its region table in one pass (tiff_analysis.py:743, 746-773): what label_equal8 + region_reduce(labels,
-    counts, cls=z, ...) return -- (labels, counts, stats, cls_out, sums, overflow) -- with the label image written once
-    by the kernel that accumulates the table."""
-    z = _req(z, torch.uint8, 3)
-    B, H, W = z.shape
-    dev = z.device
-    if cap is None:
-        cap = max(1024, (H * W) // 64)
-    labels = torch.empty((B, H, W), dtype=torch.int32, device=dev)
-    counts = torch.empty((B,), dtype=torch.int32, device=dev)
-    stats = torch.empty((B, cap, 8), dtype=torch.int64, device=dev)   # rows < counts[b] are initialised by the library
-    cls_out = torch.empty((B, cap), dtype=torch.uint8, device=dev)
-    sums = None
-    C = 0
-    if planes is not None:
-        planes = _req(planes, torch.float32, 4)
-        C = planes.shape[1]
-        sums = torch.empty((B, cap, C), dtype=torch.float64, device=dev)
-    overflow = torch.empty((B,), dtype=torch.int32, device=dev)
-    lib = _lib.load()
-    nbytes = lib.pcseg_label_regions_workspace_bytes(B, H, W)
-    ws = _ws(nbytes, dev)
-    _lib.check(lib.pcseg_label_regions_u8(_ptr(z), ctypes.c_uint64(int(sum_classes)), _ptr(planes), C, _ptr(labels), _ptr(counts),
-                                          B, H, W, cap, _ptr(stats), _ptr(cls_out), _ptr(sums), _ptr(overflow), _ptr(ws), nbytes,
-                                          _stream()), "label_regions")
-    return labels, counts, stats, cls_out, sums, overflow
 
 
 def threshold_lt(img, threshold):

@@ -114,7 +114,8 @@ def _tensors(values):
             yield from _tensors(v.values())
 
 
-_LANES = {}  # (device index, lanes) -> (executors, stream pairs): shared by every pipeline of the process
+_LANES = {}  # (device index, lanes) -> (executors, stream sets): shared by every pipeline of the process
+N_STREAMS = 5  # per lane: class chain, refinement chain (high priority), particle fill, two more merge slots
 
 
 def _lanes_for(device, lanes):
@@ -122,15 +123,23 @@ def _lanes_for(device, lanes):
     if key not in _LANES:
         from concurrent.futures import ThreadPoolExecutor
         pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix="pcseg-lane%d" % i) for i in range(lanes)]
-        streams = [(torch.cuda.Stream(device=device, priority=0), torch.cuda.Stream(device=device, priority=-1))
+        streams = [tuple(torch.cuda.Stream(device=device, priority=-1 if k == 1 else 0) for k in range(N_STREAMS))
                    for _ in range(lanes)]
         _LANES[key] = (pools, streams)
     return _LANES[key]
 
 
+def _on(stream, *tensors):
+    """Tensors made on another stream are about to be read by kernels on ``stream``: tell the caching allocator, so
+    that freeing them cannot hand their memory to new work of the producing stream while ``stream`` still reads."""
+    for t in tensors:
+        if t is not None:
+            t.record_stream(stream)
+
+
 class FramePipeline:
     def __init__(self, cell_types=None, threshold=0.5, boundary_plane=BOUNDARY_PLANE, cap=None, merged=True,
-                 watershed_mode=0, overlap=True, lanes=2):
+                 watershed_mode=0, overlap=True, lanes=2, multi_stream=True):
         self.cell_types = dict(cell_types or CELL_TYPES_5)
         self.tables_ = ops.ClassTables(self.cell_types, ta.CELL_TYPES, ta.MIN_CELL_AREA, ta.MIN_CLUSTER_AREA)
         self.threshold = float(threshold)
@@ -140,25 +149,34 @@ class FramePipeline:
         self.watershed_mode = watershed_mode
         self.overlap = overlap
         self.lanes = max(1, int(lanes))
-        self._lane_pool = None  # one single-thread executor + stream pair per lane, made on first use
+        self.multi_stream = bool(multi_stream)  # False: the class-map chain (incl. merges and fill) on ONE stream
+        self._lane_pool = None  # one single-thread executor + stream set per lane, made on first use
         self._lane_streams = None
         self._step = 0
 
     def run(self, stack):
+        """Enqueue the full chain for one batch and return at once; reading any entry of the result waits for it.
+        ``stack`` must not be modified (or refilled in place) before the result has been read or
+        ``result.synchronize()`` has returned: the kernels read it asynchronously."""
         if stack.dim() != 4 or stack.dtype != torch.float32 or not stack.is_cuda:
             raise TypeError("stack must be a (B, C, H, W) float32 CUDA tensor")
         stack = stack.contiguous()
         res = BatchResult()
         res["shape"] = tuple(stack.shape)
         if not self.overlap:
-            self._class_chain(stack, res)
+            self._class_stage(stack, res)
+            for s in self._merge_slots():
+                self._merge_stage(stack, res, s)
+            self._fill_stage(stack, res)
             self._refine_chain(stack, res)
             return res
-        # The class-map chain and the boundary-refinement chain only share the input: each gets its own HIP stream (the
-        # refinement chain, whose fixed points poll the host, the higher priority).  Consecutive batches alternate between
-        # `lanes` host threads with a stream pair each, and `run` returns at once: while one batch sits in the
-        # latency-bound tail of its watershed (small launches, host round trips) the next batch's dense kernels keep the
-        # GPU busy.  The result object waits for its lane the first time an entry is read.
+        # The chain is a small graph, not a line: the class-map stage (front end, region table, classification), the
+        # merge of each cell type and of all types together (they only need the classification), the particle fill (it
+        # only needs the denoised map) and the boundary refinement (it only needs the input) run on streams of their
+        # own, ordered by events.  Nothing in the chain waits for the host, so one host thread can keep them all fed;
+        # consecutive batches still alternate between `lanes` host threads (a stream set each) so that the launch
+        # overhead of one batch runs under the kernels of the other.  `run` returns at once; the result object waits
+        # for its lane and its closing events the first time an entry is read.
         if self._lane_pool is None or self._lane_streams[0][0].device != stack.device:
             self._lane_pool, self._lane_streams = _lanes_for(stack.device, self.lanes)
         lane = self._step % self.lanes
@@ -174,64 +192,94 @@ class FramePipeline:
             pool.submit(lambda: None).result()
         torch.cuda.synchronize()
 
+    def _merge_slots(self):
+        if not self.merged:
+            return []
+        return [s for s in range(len(self.tables_.slot_names))] + [4]
+
     def _run_lane(self, lane, stack, ready, entries):
         torch.cuda.set_device(stack.device)
         out = BatchResult(entries)  # built privately: the caller's object only receives it on synchronize()
-        s1, s2 = self._lane_streams[lane]
-        s1.wait_event(ready)
-        s2.wait_event(ready)
-        with torch.cuda.stream(s1):
-            self._class_chain(stack, out)
-        with torch.cuda.stream(s2):
+        streams = self._lane_streams[lane]
+        s_class, s_refine, s_fill, s_m1, s_m2 = streams
+        if not self.multi_stream:
+            s_fill = s_m1 = s_m2 = s_class
+        for st in streams:
+            st.wait_event(ready)
+            stack.record_stream(st)
+        with torch.cuda.stream(s_refine):
             self._refine_chain(stack, out)
-        done = (torch.cuda.Event(), torch.cuda.Event())
-        done[0].record(s1)
-        done[1].record(s2)
-        stack.record_stream(s1)
-        stack.record_stream(s2)
+        with torch.cuda.stream(s_class):
+            self._class_stage(stack, out, denoised_ready=(ev_z := torch.cuda.Event()))
+            ev_c = torch.cuda.Event()
+            ev_c.record(s_class)
+        with torch.cuda.stream(s_fill):
+            if s_fill is not s_class:
+                s_fill.wait_event(ev_z)
+                _on(s_fill, out["denoised"])
+            self._fill_stage(stack, out)
+        slots = self._merge_slots()
+        merge_streams = [s_class, s_m1, s_m2]
+        for k, slot in enumerate(slots):
+            st = merge_streams[k % len(merge_streams)]
+            with torch.cuda.stream(st):
+                if st is not s_class:
+                    st.wait_event(ev_c)
+                    _on(st, out["denoised"], out["stats"], out["region_list"], out["n_list"])
+                self._merge_stage(stack, out, slot)
+        done = []
+        for st in streams:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            done.append(ev)
         return dict(out), done
 
-    def _class_chain(self, stack, res):
+    def _class_stage(self, stack, res, denoised_ready=None):
         B, C, H, W = stack.shape
         cap = self.cap or max(1024, (H * W) // 64)
         tb = self.tables_
-        # ---- class map + denoise (A1)
-        cls = ops.argmax_planes(stack)
-        z = ops.median5(cls)
+        # ---- class map + denoise + label in one fused front end (ingest, A1, A2)
+        z, labels, counts = ops.classmap_label(stack)
         res["denoised"] = z
-        # ---- label + region table (+ isotope sums of the class components) (A2, A3, M1)
+        if denoised_ready is not None:
+            denoised_ready.record(torch.cuda.current_stream())
+        # ---- region table (+ isotope sums of the class components) (A3, M1)
         # isotope sums are only ever reported for cell / cluster regions: the planes are read under those classes only
         cell_bits = 0
         for v in tb.cell_values:
             cell_bits |= 1 << int(v)
-        labels, counts, stats, cls_out, cc_sums, overflow = ops.label_regions(z, planes=stack, cap=cap, sum_classes=cell_bits)
+        stats, cls_out, cc_sums, overflow = ops.region_reduce(labels, counts, cls=z, planes=stack, cap=cap, sum_classes=cell_bits)
         res.update(labels=labels, counts=counts, stats=stats, cls_out=cls_out, cc_sums=cc_sums, overflow=overflow)
         # ---- classification, cluster cell counts, region lists (A3 tail, A4)
         res.update(ops.classify_regions(stats, cls_out, counts, tb))
-        # ---- proximity merge per cell type and combined (A5, A6)
-        if self.merged:
-            n_slots = len(tb.slot_names)
-            bits_all = 0
-            groups = {}
-            for s in list(range(n_slots)) + [4]:
-                if s < n_slots:
-                    bits = 1 << tb.slot_value[s]
-                    bits_all |= bits
-                else:
-                    bits = bits_all
-                if bits == 0:
-                    continue
-                # dilated components as a union-find over the vertical runs of the 1-bit image: grouping only needs "same
-                # component" at the centroid pixels, so no label image is ever written
-                dbits, run_par = ops.dilated_runs(z, bits, ta.CELL_CLUSTER_DISTANCE_THRESHOLD // 2)
-                lst = res["region_list"][:, s].contiguous()
-                nl = res["n_list"][:, s].contiguous()
-                gof, ng = ops.merge_groups_runs(dbits, run_par, stats, lst, nl)
-                gst = ops.group_reduce(stats, lst, nl, gof, ng, H, W)
-                groups[s] = {"group_of": gof, "n_groups": ng, "group_stats": gst}
-            res["groups"] = groups
-        # ---- particle-area reconstruction, one fill per cell class on the previous output (A8)
-        ds = z
+        res["groups"] = {}
+
+    def _merge_stage(self, stack, res, s):
+        """proximity merge of one cell type (s < 4) or of all types together (s = 4) (A5, A6)"""
+        B, C, H, W = stack.shape
+        tb = self.tables_
+        if s < 4:
+            bits = 1 << tb.slot_value[s]
+        else:
+            bits = 0
+            for v in tb.slot_value:
+                bits |= 1 << v
+        if bits == 0:
+            return
+        # dilated components as a union-find over the vertical runs of the 1-bit image: grouping only needs "same
+        # component" at the centroid pixels, so no label image is ever written
+        dbits, run_par = ops.dilated_runs(res["denoised"], bits, ta.CELL_CLUSTER_DISTANCE_THRESHOLD // 2)
+        lst = res["region_list"][:, s].contiguous()
+        nl = res["n_list"][:, s].contiguous()
+        gof, ng = ops.merge_groups_runs(dbits, run_par, res["stats"], lst, nl)
+        gst = ops.group_reduce(res["stats"], lst, nl, gof, ng, H, W)
+        res["groups"][s] = {"group_of": gof, "n_groups": ng, "group_stats": gst}
+
+    def _fill_stage(self, stack, res):
+        """particle-area reconstruction, one fill per cell class on the previous output (A8)"""
+        B = stack.shape[0]
+        tb = self.tables_
+        ds = res["denoised"]
         overlap = torch.zeros((B,), dtype=torch.int64, device=stack.device)
         if tb.particle_value is not None:
             for v in tb.cell_values:

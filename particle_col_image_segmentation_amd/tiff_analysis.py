@@ -123,7 +123,8 @@ def label(image):
 
 
 def _regions_of(z_dev):
-    """label + regionprops of one frame on the device; returns (regions, label image holder, stats tensor)."""
+    """label + regionprops of one frame on the device: (regions, class at first pixel, label holder, and the device
+    tensors stats / cls_out / counts that the classification and merge kernels take)."""
     labels, counts = ops.label_equal8(z_dev)
     n = int(counts[0].item())
     stats, cls_out, _, _ = ops.region_reduce(labels, counts, cls=z_dev, cap=max(n, 1))
@@ -132,7 +133,7 @@ def _regions_of(z_dev):
     cl = cls_out[0, :n].cpu().numpy()
     width = z_dev.shape[2]
     regions = [Region(i + 1, st[i], width, holder) for i in range(n)]
-    return regions, cl, holder, stats
+    return regions, cl, holder, (stats, cls_out, counts)
 
 
 def regionprops(label_im):
@@ -157,38 +158,40 @@ def get_type(region, data):
 
 
 def get_cell_positions_and_areas(z_slice, cell_types, merged=False):
-    """tiff_analysis.py:742-789.  Returns (cell_pos, cell_clusters, particle_area, merged_clusters)."""
+    """tiff_analysis.py:742-789.  Returns (cell_pos, cell_clusters, particle_area, merged_clusters).
+
+    The per-region decisions (Particle area, cell / cluster by the area thresholds of the region's type, cluster cell
+    count = int(area // mean single-cell area)) are ``pcseg_classify_regions`` -- the kernel the batched pipeline uses
+    -- and the host only files the regions under their type names."""
     z_dev, _ = _to_dev_u8(z_slice)
-    regions, classes, _, stats = _regions_of(z_dev)
-    cell_pos, cell_clusters, particle_area = {}, {}, 0
-    for region, region_type in zip(regions, classes):
-        cell_type = cell_types[int(region_type)]  # KeyError for an unmapped class value, like the reference (:756)
-        if cell_type not in CELL_TYPES:
-            if cell_type == "Particle":
-                particle_area += region.area
-            continue
-        min_cell_area = MIN_CELL_AREA[cell_type]
-        min_cluster_area = MIN_CLUSTER_AREA[cell_type]
-        if cell_type not in cell_pos:
-            cell_pos[cell_type] = []
-            cell_clusters[cell_type] = []
-        if min_cell_area <= region.area < min_cluster_area:
-            cell_pos[cell_type].append(region)
-        if region.area >= min_cluster_area:
-            cell_clusters[cell_type].append(region)
-    cell_area_averages = {}
-    for cell_type, cell_array in cell_pos.items():
-        with np.errstate(all="ignore"):
-            cell_area_averages[cell_type] = (np.average([np.int64(c.area) for c in cell_array])
-                                             if cell_array else np.float64("nan"))
-    for cell_type, cluster_array in cell_clusters.items():
-        for cluster in cluster_array:
-            # int(NaN) raises ValueError exactly like the reference when a type has clusters but no single cell
-            cluster.cells = int(np.int64(cluster.area) // cell_area_averages[cell_type])
+    regions, classes, _, (stats, cls_out, counts) = _regions_of(z_dev)
+    for value in np.unique(classes):
+        cell_types[int(value)]  # KeyError for an unmapped class value, as at :756
+    tables = ops.ClassTables(cell_types, CELL_TYPES, MIN_CELL_AREA, MIN_CLUSTER_AREA)
+    verdict = ops.classify_regions(stats, cls_out, counts, tables)
+    n = len(regions)
+    kind = verdict["kind"][0, :n].cpu().numpy()
+    slot = verdict["slot_of"][0, :n].cpu().numpy()
+    n_cells = verdict["cells"][0, :n].cpu().numpy()
+    first_region = verdict["type_stats"][0, :, 3].cpu().numpy()
+    # the reference's dicts are keyed in the order the types first appear among the regions (:763-765)
+    order = sorted((int(first_region[t]), t) for t in range(len(tables.slot_names)) if first_region[t] != 0x7FFFFFFF)
+    cell_pos = {tables.slot_names[t]: [] for _, t in order}
+    cell_clusters = {tables.slot_names[t]: [] for _, t in order}
+    if int(verdict["nan_flag"][0].item()):
+        # a type with clusters but without a single cell: np.average([]) is NaN and int(NaN) raises (:776-781)
+        raise ValueError("cannot convert float NaN to integer")
+    for i in np.nonzero(kind)[0]:
+        name = tables.slot_names[slot[i]]
+        if kind[i] == 1:
+            cell_pos[name].append(regions[i])
+        else:
+            regions[i].cells = int(n_cells[i])
+            cell_clusters[name].append(regions[i])
+    particle_area = int(verdict["particle_area"][0].item())
+    merged_clusters = {}
     if merged:
         merged_clusters, _ = _clusters_from_distances(z_dev, stats, cell_pos, cell_clusters, cell_types, False)
-    else:
-        merged_clusters = {}
     return cell_pos, cell_clusters, particle_area, merged_clusters
 
 
@@ -201,18 +204,16 @@ def _group_regions(dl_dev, stats_dev, og_cell_regions):
         lst[0, :n] = torch.tensor([r.label - 1 for r in og_cell_regions], dtype=torch.int32)
     group_of, n_groups = ops.merge_groups(dl_dev, stats_dev, lst.to(dev), torch.tensor([n], dtype=torch.int32, device=dev))
     gof = group_of[0, :n].cpu().numpy()
-    groups = [[] for _ in range(int(n_groups[0].item()))]
-    for r, g in zip(og_cell_regions, gof):
-        if g > 0:
-            groups[g - 1].append(r)
     merged_regions = []
-    for touching in groups:
+    for g in range(1, int(n_groups[0].item()) + 1):
+        members = [og_cell_regions[k] for k in np.nonzero(gof == g)[0]]
+        areas = [m.area for m in members]
+        boxes = np.array([m.bbox for m in members])
         merged_regions.append({
-            "area": sum(r.area for r in touching),
-            "centroid": np.average([r.centroid for r in touching], axis=0, weights=[r.area for r in touching]),
-            "regions": touching,
-            "bbox": (min(r.bbox[0] for r in touching), min(r.bbox[1] for r in touching),
-                     max(r.bbox[2] for r in touching), max(r.bbox[3] for r in touching)),
+            "area": sum(areas),
+            "centroid": np.average([m.centroid for m in members], axis=0, weights=areas),
+            "regions": members,
+            "bbox": (boxes[:, 0].min(), boxes[:, 1].min(), boxes[:, 2].max(), boxes[:, 3].max()),
         })
     return merged_regions, gof
 
@@ -246,26 +247,22 @@ def _merged_regions_dev(z_dev, value_bits, stats_dev, og_cell_regions, want_imag
 
 
 def _clusters_from_distances(z_dev, stats_dev, cell_pos, cell_clusters, cell_types, want_images):
-    combined = {}
-    # the reference iterates a set of the type names (hash-randomised order, :794); insertion order here
-    for key in list(cell_pos) + [k for k in cell_clusters if k not in cell_pos]:
-        combined[key] = cell_pos.get(key, []) + cell_clusters.get(key, [])
-    merged_regions, merged_images, img_vals, combined_regions = {}, {}, [], []
-    for cell_type, cell_regions in combined.items():
-        cell_img_val = 0
-        for cell_val, cell_temp_type in cell_types.items():
-            if cell_temp_type == cell_type:
-                cell_img_val = cell_val
-                break
-        img_vals.append(cell_img_val)
-        combined_regions.extend(cell_regions)
-        merged_regions[cell_type], merged_images[cell_type] = _merged_regions_dev(
-            z_dev, 1 << cell_img_val, stats_dev, cell_regions, want_images)
-    bits = 0
-    for v in img_vals:
-        bits |= 1 << v
-    merged_regions["combined"], merged_images["combined"] = _merged_regions_dev(
-        z_dev, bits, stats_dev, combined_regions, want_images)
+    """:791-824 on the device: one dilated-mask grouping per cell type over that type's cells + clusters, and one over
+    all of them on the union of the masks ("combined").  The reference walks a set of the type names (hash-randomised
+    order, :794); here the types come in the insertion order of the two dicts."""
+    names = list(cell_pos) + [k for k in cell_clusters if k not in cell_pos]
+    first_value = {}
+    for value, name in cell_types.items():
+        first_value.setdefault(name, value)  # the class value of a type is the FIRST key that maps to it (:806-810)
+    merged_regions, merged_images = {}, {}
+    everything, all_bits = [], 0
+    for name in names:
+        members = cell_pos.get(name, []) + cell_clusters.get(name, [])
+        value = first_value.get(name, 0)
+        all_bits |= 1 << value
+        everything += members
+        merged_regions[name], merged_images[name] = _merged_regions_dev(z_dev, 1 << value, stats_dev, members, want_images)
+    merged_regions["combined"], merged_images["combined"] = _merged_regions_dev(z_dev, all_bits, stats_dev, everything, want_images)
     return merged_regions, merged_images
 
 
@@ -287,15 +284,10 @@ def get_merged_regions(binary_image, og_cell_regions):
     return merged_regions, _back(merged_image, was)
 
 
-def _fill_particle_dev(ds_dev, particle_label, cell_label, overlap_label):
-    out, area = ops.fill_particle(ds_dev, particle_label, cell_label, overlap_label, DILATION_RADIUS, DISTANCE_THRESHOLD)
-    return out, area
-
-
 def fill_particle_area(ds_arr, particle_label, cell_label, overlap_label):
     """tiff_analysis.py:982-1015.  Returns (updated_ds_arr, overlap_area); the input is not modified (:1010)."""
     ds_dev, was = _to_dev_u8(ds_arr)
-    out, area = _fill_particle_dev(ds_dev, particle_label, cell_label, overlap_label)
+    out, area = ops.fill_particle(ds_dev, particle_label, cell_label, overlap_label, DILATION_RADIUS, DISTANCE_THRESHOLD)
     res = _back(out[0], was)
     if not was:
         res = res.astype(np.asarray(ds_arr).dtype, copy=False)
@@ -303,47 +295,41 @@ def fill_particle_area(ds_arr, particle_label, cell_label, overlap_label):
 
 
 def recreate_particle_area(ds_arr, cell_types, particle_area):
-    """tiff_analysis.py:931-950: one fill per cell class, each on the output of the previous one."""
-    particle_label = None
-    for key, value in cell_types.items():
-        if value == "Particle":
-            particle_label = key
-    ds_dev, was = _to_dev_u8(ds_arr)
-    touched = False
-    for cell_type_label, cell_type in cell_types.items():
-        if cell_type not in CELL_TYPES:
-            continue
-        if particle_label is None:
-            raise TypeError("no 'Particle' entry in cell_types")  # the reference fails inside fill_particle_area
-        ds_dev, area = _fill_particle_dev(ds_dev, particle_label, cell_type_label, particle_label)
-        particle_area += int(area[0].item())
-        touched = True
-    if not touched:
+    """tiff_analysis.py:931-950: one fill per cell class, each on the output of the previous one; the overlap areas
+    are accumulated on the device and read once."""
+    cell_labels = [label for label, name in cell_types.items() if name in CELL_TYPES]
+    if not cell_labels:
         return ds_arr, particle_area
+    particle_labels = [label for label, name in cell_types.items() if name == "Particle"]
+    if not particle_labels:
+        raise TypeError("no 'Particle' entry in cell_types")  # the reference fails inside fill_particle_area
+    particle_label = particle_labels[-1]  # the last match wins in the reference's loop (:933-935)
+    ds_dev, was = _to_dev_u8(ds_arr)
+    gained = None
+    for cell_label in cell_labels:
+        ds_dev, gained = ops.fill_particle(ds_dev, particle_label, cell_label, particle_label, DILATION_RADIUS,
+                                           DISTANCE_THRESHOLD, gained)
     res = _back(ds_dev[0], was)
     if not was:
         res = res.astype(np.asarray(ds_arr).dtype, copy=False)
-    return res, particle_area
+    return res, particle_area + int(gained[0].item())
 
 
 def get_cell_counts_and_densities(cell_pos, cell_clusters, particle_area):
-    """tiff_analysis.py:1018-1038 (host arithmetic on the region table)."""
-    cell_count, cell_density, cell_area_ratio = {}, {}, {}
-    particle_area = particle_area / (PX_TO_UM_CONV ** 2)
-    for cell_type, cell_array in cell_pos.items():
-        if cell_type not in CELL_TYPES:
-            continue
-        cluster_cells = 0
-        for cluster in cell_clusters[cell_type]:
-            cluster_cells += cluster.cells
-        cell_count[cell_type] = len(cell_array) + cluster_cells
-        cell_area = np.sum([np.int64(cell.area) for cell in cell_array])
-        for cluster in cell_clusters[cell_type]:
-            cell_area += cluster["area"]
-        area = cell_area / (PX_TO_UM_CONV ** 2)
-        cell_density[cell_type] = round(cell_count[cell_type] / particle_area, 5)
-        cell_area_ratio[cell_type] = round(area / particle_area, 5)
-    return cell_count, cell_density, cell_area_ratio
+    """tiff_analysis.py:1018-1038: count = cells + cells inside clusters; density and area ratio per um^2 of particle,
+    both rounded to 5 decimals (Python's round on a Python float, as there)."""
+    um2 = PX_TO_UM_CONV ** 2
+    particle_um2 = particle_area / um2
+    counts, densities, ratios = {}, {}, {}
+    for name in (t for t in cell_pos if t in CELL_TYPES):
+        clusters = cell_clusters[name]
+        counts[name] = len(cell_pos[name]) + sum(c.cells for c in clusters)
+        pixels = np.sum([np.int64(c.area) for c in cell_pos[name]])  # np.sum([]) is 0.0, like the reference's
+        for c in clusters:
+            pixels = pixels + c["area"]
+        densities[name] = round(counts[name] / particle_um2, 5)
+        ratios[name] = round((pixels / um2) / particle_um2, 5)
+    return counts, densities, ratios
 
 
 def combine_cell_positions_and_clusters(dapi_channel, other_channel):
@@ -423,12 +409,10 @@ def get_cell_type_map_from_channel(strain_types, channel):
 
 
 def get_pos_and_density_file_names(cur_folder):
-    """tiff_analysis.py:619-624."""
-    cur_folder_split = cur_folder.split("/")
-    density_info_file_name = f"{cur_folder_split[-3]}_{cur_folder_split[-2]}_cell_density_info.csv"
-    density_info_file_path = os.path.join(cur_folder, "..", density_info_file_name)
-    cell_pos_file_name = os.path.join(cur_folder, f"{cur_folder_split[-1]}_cell_pos.csv")
-    return density_info_file_path, cell_pos_file_name
+    """tiff_analysis.py:619-624: (<grandparent>_<parent>_cell_density_info.csv next to the folder, <folder>_cell_pos.csv in it)."""
+    parts = cur_folder.split("/")
+    density_csv = os.path.join(cur_folder, "..", "%s_%s_cell_density_info.csv" % (parts[-3], parts[-2]))
+    return density_csv, os.path.join(cur_folder, parts[-1] + "_cell_pos.csv")
 
 
 def _um2(area_px):
@@ -512,23 +496,18 @@ def read_class_map(path):
 
 
 def process_single_h5_file(cur_folder, file_path):
-    """tiff_analysis.py:627-671 without the matplotlib figures: the three CSVs."""
-    full_file_path = os.path.join(cur_folder, file_path)
-    density_info_file_path, cell_pos_file_name = get_pos_and_density_file_names(cur_folder)
-    processed_folder = cur_folder.split("/")[-1]
+    """tiff_analysis.py:627-671 without the matplotlib figures: position CSV, merged-position CSV, density row."""
     cell_types = get_cell_type_map(file_path)
-    if len(cell_types) == 0:
+    if not cell_types:
         raise ValueError("Cell type not found in file path")
-    ds_arr = normalize_ds_arr(read_class_map(full_file_path))
-    ds_arr_denoised = median_filter(ds_arr, size=DENOISE_SIZE)
-    cell_positions, cell_clusters, particle_area, merged_clusters = get_cell_positions_and_areas(
-        ds_arr_denoised, cell_types, merged=True)
-    cell_count, cell_density, cell_area_ratio = get_cell_counts_and_densities(cell_positions, cell_clusters, particle_area)
-    _, particle_area = recreate_particle_area(ds_arr_denoised, cell_types, particle_area)
-    write_cell_position_info(cell_positions, cell_clusters, cell_pos_file_name, particle_area)
-    merged_file_name = cell_pos_file_name.replace("_cell_pos.csv", "_merged_cell_pos.csv")
-    write_merged_cell_position_info(merged_clusters, merged_file_name, particle_area)
-    write_density_info(density_info_file_path, processed_folder, cell_density, cell_area_ratio, cell_count)
+    density_csv, cell_pos_csv = get_pos_and_density_file_names(cur_folder)
+    denoised = median_filter(normalize_ds_arr(read_class_map(os.path.join(cur_folder, file_path))), size=DENOISE_SIZE)
+    positions, clusters, particle_area, merged = get_cell_positions_and_areas(denoised, cell_types, merged=True)
+    counts, densities, ratios = get_cell_counts_and_densities(positions, clusters, particle_area)  # BEFORE the particle fill (:652)
+    _, particle_area = recreate_particle_area(denoised, cell_types, particle_area)
+    write_cell_position_info(positions, clusters, cell_pos_csv, particle_area)
+    write_merged_cell_position_info(merged, cell_pos_csv.replace("_cell_pos.csv", "_merged_cell_pos.csv"), particle_area)
+    write_density_info(density_csv, cur_folder.split("/")[-1], densities, ratios, counts)
 
 
 def _analyse_channel_file(cur_folder, file, cell_strains):

@@ -162,7 +162,14 @@ def test_batches_in_flight_do_not_interfere():
         ref = solo.run(st)
         torch.cuda.synchronize()
         for k in keys:
+            if k in ("stats", "ws_stats"):  # rows beyond the frame's count are not initialised (no 110 MB zero fill)
+                cnt = res["counts" if k == "stats" else "n_markers"]
+                for b in range(st.shape[0]):
+                    assert torch.equal(res[k][b, :int(cnt[b])], ref[k][b, :int(cnt[b])]), k
+                continue
             assert torch.equal(res[k], ref[k]), k
-        np.testing.assert_allclose(res["ws_sums"].cpu().numpy(), ref["ws_sums"].cpu().numpy(), rtol=1e-9, atol=1e-9)
+        for b in range(st.shape[0]):
+            m = int(res["n_markers"][b])
+            np.testing.assert_allclose(res["ws_sums"][b, :m].cpu().numpy(), ref["ws_sums"][b, :m].cpu().numpy(), rtol=1e-9, atol=1e-9)
     pipe.synchronize()
 

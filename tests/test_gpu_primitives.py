@@ -316,27 +316,26 @@ def test_refine_chain_batch(ops):
             np.testing.assert_array_equal(host(labels)[i], ref["labels"])
 
 
-def test_label_regions_fused_equals_two_step(ops):
-    """pcseg_label_regions_u8 (numbering decoded inside the reduction) against label + region_reduce, on widths that
-    take the fused kernel (W % 4 == 0) and on one that takes the two-step fallback."""
+def test_classmap_label_fused_equals_separate_kernels(ops):
+    """pcseg_classmap_label_f32 (argmax + median + union-find tile pass in one kernel) against the three separate calls
+    and the oracle: full-width tiles, ragged widths / heights, 3-, 4-, 5- and 7-plane stacks (7: the unfused route)."""
     from particle_col_image_segmentation_amd import synth
-    for (H, W) in ((160, 192), (97, 132), (64, 130), (33, 64)):
-        st = synth.gen_batch(70, 3, H, W)
-        cm = np.stack([orc.median_filter(c) for c in synth.class_map_from_stack(st)])
-        labels, counts = ops.label_equal8(dev(cm))
-        stats, cls_out, sums, ovf = ops.region_reduce(labels, counts, cls=dev(cm), planes=dev(st), cap=4096, sum_classes=0b110)
-        l2, c2, s2, co2, su2, ov2 = ops.label_regions(dev(cm), planes=dev(st), cap=4096, sum_classes=0b110)
-        assert torch.equal(l2, labels) and torch.equal(c2, counts) and int(ov2.sum()) == 0
-        for b in range(3):
-            n = int(counts[b])
-            np.testing.assert_array_equal(host(l2)[b], orc.label(cm[b]))
-            assert torch.equal(s2[b, :n], stats[b, :n]) and torch.equal(co2[b, :n], cls_out[b, :n])
-            np.testing.assert_allclose(host(su2)[b, :n], host(sums)[b, :n], rtol=1e-12, atol=0)
-        # without planes, and with a capacity that is too small
-        l3, c3, s3, co3, su3, ov3 = ops.label_regions(dev(cm), cap=4096)
-        assert su3 is None and torch.equal(l3, labels) and all(torch.equal(s3[b, :int(counts[b])], stats[b, :int(counts[b])]) for b in range(3))
-        l4, c4, s4, co4, su4, ov4 = ops.label_regions(dev(cm), cap=2)
-        assert torch.equal(l4, labels) and int(ov4.min()) == 1
+    for (H, W, C) in ((160, 192, 5), (97, 132, 5), (64, 130, 5), (33, 64, 4), (70, 257, 3), (40, 72, 7), (5, 3, 5), (130, 64, 2)):
+        st = synth.gen_batch(70, 2, H, W)
+        if C <= 5:
+            st = np.ascontiguousarray(st[:, :C])
+        else:
+            st = np.ascontiguousarray(np.concatenate([st, st[:, :C - 5] * 0.5], axis=1))
+        cls = ops.argmax_planes(dev(st))
+        z_ref = ops.median5(cls)
+        lab_ref, cnt_ref = ops.label_equal8(z_ref)
+        z, lab, cnt = ops.classmap_label(dev(st))
+        assert torch.equal(z, z_ref) and torch.equal(lab, lab_ref) and torch.equal(cnt, cnt_ref), (H, W, C)
+        for b in range(2):
+            cm = (np.argmax(st[b], axis=0) + 1).astype(np.uint8)
+            den = orc.median_filter(cm)
+            np.testing.assert_array_equal(host(z)[b], den)
+            np.testing.assert_array_equal(host(lab)[b], orc.label(den))
 
 
 def test_merge_groups(ops):
