@@ -83,14 +83,30 @@ def cpu_baseline(res, stack, cell_types, n_frames):
     per = [r["seconds"] for r in refs]
     block = {"value": round(n * H * W / wall / 1e6, 4), "unit": "Mpixels/s", "cores": procs, "kind": "port",
              "sample": "the first %d frames (%dx%dx5) of the timed batch, full chain incl. O(R) merge, %d processes, "
-                       "wall %.1f s (%.2f s/frame/core); reference (Python, scikit-image) measured in the build "
-                       "container on this generator: see BASELINE.md" % (n, H, W, procs, wall, sum(per) / len(per))}
+                       "wall %.1f s (%.2f s/frame/core)" % (n, H, W, procs, wall, sum(per) / len(per))}
+    # how the port relates to the real reference (Python + scikit-image, which cannot travel to this box): measured in
+    # the build container by oracle/measure_reference.py on this generator -- incl. the reference's merge AS WRITTEN,
+    # whose O(R^2) list comprehension (tiff_analysis.py:850-852) dominates its CPU path
+    ratio_path = os.path.join(ROOT, "oracle", "reference_ratio.json")
+    if os.path.exists(ratio_path):
+        ratio = json.load(open(ratio_path))
+        block["reference_vs_port"] = {
+            "measured": ratio["where"] + "; " + ratio["reference_versions"],
+            "reference_s_per_frame_no_merge": ratio["reference_chain_no_merge_s_per_frame"],
+            "port_s_per_frame_no_merge": ratio["oracle_chain_no_merge_s_per_frame"],
+            "reference_merge_as_written_s_per_frame": ratio["reference_merge_as_written_s"],
+            "reference_merge_regions": ratio["reference_merge_as_written_regions"],
+            "port_s_per_frame_with_OR_merge": ratio["oracle_chain_with_OR_merge_s_per_frame"],
+            "reference_over_port_no_merge": ratio["reference_over_oracle_no_merge"],
+            "reference_with_merge_as_written_over_port": ratio["reference_with_merge_over_oracle_with_merge"],
+            "reference_with_merge_Mpixels_per_s_per_core_estimate": round(
+                H * W / 1e6 / (ratio["reference_chain_no_merge_s_per_frame"] + ratio["reference_merge_as_written_s"]), 4)}
     return block, checked
 
 
 def end_to_end_leg(args, stack, cell_types, pipe, dev, world, kernel_only_mpx):
     """What a dataset run costs beyond the kernels (BASELINE configs 3 / 5 code path, per rank): `distributed.run_sharded`
-    over a dataset of 4 batches per rank (the resident batch stands in for every batch: generation is not what is
+    over a dataset of 6 batches per rank (the resident batch stands in for every batch: generation is not what is
     measured) = kernel chain + device-side table assembly + table download + the all-gather of every table; and the
     same chain fed over PCIe from pinned host memory through `ingest.FrameUploader` (double-buffered copies on a
     stream of their own).  Neither figure is `value` (inputs resident in HBM, by contract)."""
@@ -98,7 +114,7 @@ def end_to_end_leg(args, stack, cell_types, pipe, dev, world, kernel_only_mpx):
     from particle_col_image_segmentation_amd.distributed import run_sharded
     from particle_col_image_segmentation_amd.ingest import FrameUploader
     B, C, H, W = stack.shape
-    n_batches = 4
+    n_batches = 6
     n_frames = n_batches * B * world
     make_batch = lambda ids: stack[:len(ids)]
     run_sharded(B * world, make_batch, pipe, batch=B, device=dev, check=False)  # warm (sort kernels, table buffers)
@@ -151,6 +167,7 @@ def secondary_leg(args, stack, cell_types, pipe):
     del res
     big[:, 3] = torch.round(big[:, 3] * 100) / 100
     torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
     res = solo.run(big)
     res.synchronize()
@@ -165,7 +182,8 @@ def secondary_leg(args, stack, cell_types, pipe):
     return {"workload": "boundary plane quantised to k/100 (random-forest vote fractions): ONE batch of %d frames %dx%dx5 "
                         "(the headline batch repeated %d times), full kernel chain, inputs resident in HBM" % (n, H, W, reps),
             "value": round(n * H * W / dt / 1e6, 3), "unit": "Mpixels/s", "steps": 1, "ms_per_step": round(1e3 * dt, 1),
-            "frames": n, "tie_fallback_frames": ties, "parity_checked_frames": checked}
+            "frames": n, "tie_fallback_frames": ties, "parity_checked_frames": checked,
+            "peak_device_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
 
 
 class _StdoutToStderr:

@@ -225,9 +225,12 @@ __global__ void __launch_bounds__(256) ccl_scan_blocks_kernel(int *__restrict__ 
     if (threadIdx.x == 0 && counts) counts[blockIdx.x] = carry;
 }
 
+// chase: the parents are not flattened (the counting pass only looked for roots, parent[i] == i): every pixel walks to
+// its root here -- one or two more dependent loads in a streaming, fully occupied kernel instead of a flatten pass
+// that reads and rewrites the whole union-find image
 template <typename Pred>
 __global__ void __launch_bounds__(256) ccl_relabel_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
-                                                           Pred pred, int64_t n, int nblk)
+                                                           Pred pred, int64_t n, int nblk, bool chase)
 {
     const int b = blockIdx.y;
     const int *par = parent + (int64_t)b * n;
@@ -243,9 +246,20 @@ __global__ void __launch_bounds__(256) ccl_relabel_kernel(const int *__restrict_
             if (i0 + j < n) pv[j] = par[i0 + j];
     }
     int out[4];
+    int root_of_prev = -1, prev_p = -2;
     for (int j = 0; j < 4; ++j) {
-        const int p = pv[j];
+        int p = pv[j];
         int v = 0;
+        if (chase && p >= 0) {
+            if (p == prev_p) {
+                p = root_of_prev;  // same entry as the pixel to the left: its walk is the answer
+            } else {
+                prev_p = p;
+                int q;
+                while ((q = par[p]) != p) p = q;
+                root_of_prev = p;
+            }
+        }
         if (p >= 0 && pred((int64_t)b * n + p)) {
             v = __hip_atomic_load(lab + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // rank code or final label
             if (v < 0) v = blockoff[b * nblk + p / SCAN_PIX] - v;
@@ -285,11 +299,13 @@ static CclWs ccl_carve(Carver &cv, int B, int H, int W)
 }
 
 template <typename KeyFn, bool CONN8>
-static int ccl_roots(KeyFn keyfn, int *parent, int B, int H, int W, hipStream_t s)
+static int ccl_roots(KeyFn keyfn, int *parent, int B, int H, int W, hipStream_t s, bool tile_pass_done = false)
 {
     dim3 tgrid((W + CCL_TW - 1) / CCL_TW, (H + CCL_TH - 1) / CCL_TH, B);
-    PCSEG_LAUNCH((ccl_tile_kernel<KeyFn, CONN8>), tgrid, dim3(256), 0, s, keyfn, parent, H, W);
-    PCSEG_CHECK_LAUNCH();
+    if (!tile_pass_done) {
+        PCSEG_LAUNCH((ccl_tile_kernel<KeyFn, CONN8>), tgrid, dim3(256), 0, s, keyfn, parent, H, W);
+        PCSEG_CHECK_LAUNCH();
+    }
     if (tgrid.x > 1 || tgrid.y > 1) {
         const int64_t border_px = (int64_t)((H - 1) / CCL_TH) * W + (int64_t)(CONN8 ? 2 : 1) * ((W - 1) / CCL_TW) * H;
         dim3 bgrid((unsigned)((border_px + 255) / 256), B);
@@ -306,11 +322,14 @@ static int ccl_compact(int *parent, int *blockcount, int nblk, int *labels, int 
 {
     int64_t n = (int64_t)H * W;
     dim3 grid(nblk, B);
-    PCSEG_LAUNCH((ccl_flatten_count_kernel<Pred>), grid, dim3(256), 0, s, parent, labels, blockcount, pred, n, nblk, flatten);
+    // roots are exact after the border pass (parent[i] == i), so they can be counted and ranked without flattening;
+    // `flatten` (the parents are not flat yet) only tells the relabel pass to walk to the roots itself
+    PCSEG_LAUNCH((ccl_flatten_count_kernel<Pred>), grid, dim3(256), 0, s, parent, labels, blockcount, pred, n, nblk, false);
     PCSEG_CHECK_LAUNCH();
     PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, blockcount, counts, nblk);
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH((ccl_relabel_kernel<Pred>), grid, dim3(256), 0, s, (const int *)parent, labels, (const int *)blockcount, pred, n, nblk);
+    PCSEG_LAUNCH((ccl_relabel_kernel<Pred>), grid, dim3(256), 0, s, (const int *)parent, labels, (const int *)blockcount, pred, n, nblk,
+                 flatten);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }
@@ -612,21 +631,28 @@ __global__ void __launch_bounds__(256) ccl_flatten_kernel(int *__restrict__ pare
 }
 
 // ---- local maxima ----------------------------------------------------------
-// One stencil pass over a 64x16 tile staged in LDS with a 2-pixel halo: candidates (no higher 8-neighbour) are
+// One stencil pass over a 64x32 tile staged in LDS with a 2-pixel halo: candidates (no higher 8-neighbour) are
 // determined for the tile and the ring around it, so the same pass can also tell which candidate pixels touch an
 // equal-valued NON-candidate -- the pixels that spoil their plateau.  That flag is left at the pixel's own slot of
 // `bad`; after the components of the candidates are known, locmax_propagate_kernel flattens the parents and raises
 // bad[root] for every flagged pixel (own-slot flags of non-root pixels are never read as root flags).
-constexpr int LM_TW = 64, LM_TH = 16, LM_SW = LM_TW + 4, LM_SH = LM_TH + 4, LM_CW = LM_TW + 2, LM_CH = LM_TH + 2;
+constexpr int LM_TW = CCL_TW, LM_TH = CCL_TH, LM_SW = LM_TW + 4, LM_SH = LM_TH + 4, LM_CW = LM_TW + 2, LM_CH = LM_TH + 2;
 
-__global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__restrict__ img, int *__restrict__ key,
-                                                                 uint8_t *__restrict__ bad, int *__restrict__ nonconst, int H, int W)
+// ... and the union-find tile pass of the candidates' plateaus (equal-valued 8-connected candidates) runs in the same
+// kernel on the keys while they are still in LDS: the key image is written for the border pass but never read back
+// by a tile pass of its own.
+__global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__restrict__ img, int *__restrict__ key_out,
+                                                                 uint8_t *__restrict__ bad, int *__restrict__ nonconst,
+                                                                 int *__restrict__ parent, int H, int W)
 {
     __shared__ int tile[LM_SH * LM_SW];
     __shared__ uint8_t cand[LM_CH * LM_CW];  // tile + 1 ring: 0 inside and not a candidate, 1 candidate, 2 outside the image
+    __shared__ int key[CCL_TILE];
+    __shared__ int par[CCL_TILE];
     const int OUTSIDE = (int)0x80000000;  // image values are > INT_MIN by contract: never higher, never "different"
-    const int r0 = blockIdx.y * LM_TH, c0 = blockIdx.x * LM_TW;
-    const int64_t fbase = (int64_t)blockIdx.z * H * W;
+    const TileIndex ti = xcd_tile_index();
+    const int r0 = ti.y * LM_TH, c0 = ti.x * LM_TW;
+    const int64_t fbase = (int64_t)ti.z * H * W;
     for (int i = threadIdx.x; i < LM_SH * LM_SW; i += 256) {
         int r = r0 + i / LM_SW - 2, c = c0 + i % LM_SW - 2;
         tile[i] = (r >= 0 && r < H && c >= 0 && c < W) ? img[fbase + (int64_t)r * W + c] : OUTSIDE;
@@ -659,25 +685,32 @@ __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__res
     for (int t = threadIdx.x; t < LM_TH * LM_TW; t += 256) {
         const int lr = t / LM_TW, lc = t % LM_TW;
         const int r = r0 + lr, c = c0 + lc;
-        if (r >= H || c >= W) continue;
-        const int i = (lr + 2) * LM_SW + lc + 2, j = (lr + 1) * LM_CW + lc + 1;
-        const int v = tile[i];
-        const bool is_cand = cand[j] == 1;
-        bool touches = false;
-        if (is_cand) {
+        int k = 0;
+        if (r < H && c < W) {
+            const int i = (lr + 2) * LM_SW + lc + 2, j = (lr + 1) * LM_CW + lc + 1;
+            const int v = tile[i];
+            const bool is_cand = cand[j] == 1;
+            bool touches = false;
+            if (is_cand) {
 #pragma unroll
-            for (int dr = -1; dr <= 1; ++dr)
+                for (int dr = -1; dr <= 1; ++dr)
 #pragma unroll
-                for (int dc = -1; dc <= 1; ++dc) {
-                    if (dr == 0 && dc == 0) continue;
-                    touches = touches || (cand[j + dr * LM_CW + dc] == 0 && tile[i + dr * LM_SW + dc] == v);
-                }
+                    for (int dc = -1; dc <= 1; ++dc) {
+                        if (dr == 0 && dc == 0) continue;
+                        touches = touches || (cand[j + dr * LM_CW + dc] == 0 && tile[i + dr * LM_SW + dc] == v);
+                    }
+            }
+            // key must be non-zero for candidates and equal exactly when the values are equal (values > INT_MIN)
+            k = is_cand ? (v == 0 ? (int)0x80000000 : v) : 0;
+            key_out[fbase + (int64_t)r * W + c] = k;
+            bad[fbase + (int64_t)r * W + c] = touches ? 1 : 0;
         }
-        // key must be non-zero for candidates and equal exactly when the values are equal (values > INT_MIN)
-        key[fbase + (int64_t)r * W + c] = is_cand ? (v == 0 ? (int)0x80000000 : v) : 0;
-        bad[fbase + (int64_t)r * W + c] = touches ? 1 : 0;
+        key[t] = k;
     }
-    if (__any(any_differs) && lane_id() == 0 && nonconst[blockIdx.z] == 0) nonconst[blockIdx.z] = 1;
+    if (__any(any_differs) && lane_id() == 0 && nonconst[ti.z] == 0) nonconst[ti.z] = 1;
+    __syncthreads();
+    ccl_tile_unions<true>(key, par);
+    ccl_tile_store(key, par, parent, fbase, r0, c0, H, W);
 }
 
 // flatten the candidates' parents and move every pixel's own flag to its root
@@ -912,9 +945,9 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
     }
     PCSEG_CHECK_HIP(hipMemsetAsync(nonconst, 0, sizeof(int) * B, s));
     dim3 g2((W + LM_TW - 1) / LM_TW, (H + LM_TH - 1) / LM_TH, B);
-    PCSEG_LAUNCH(locmax_candidates_kernel, g2, dim3(256), 0, s, img, key, bad, nonconst, H, W);  // writes every slot of `bad`
+    PCSEG_LAUNCH(locmax_candidates_kernel, g2, dim3(256), 0, s, img, key, bad, nonconst, ws.parent, H, W);  // writes every slot of `bad`
     PCSEG_CHECK_LAUNCH();
-    int rc = ccl_roots<KeyI32, true>(KeyI32{key, W, (int64_t)H * W}, ws.parent, B, H, W, s);
+    int rc = ccl_roots<KeyI32, true>(KeyI32{key, W, (int64_t)H * W}, ws.parent, B, H, W, s, true);  // tile pass: done above
     if (rc) return rc;
     dim3 g1((unsigned)((n + 255) / 256), B);
     PCSEG_LAUNCH(locmax_propagate_kernel, g1, dim3(256), 0, s, ws.parent, bad, n);

@@ -83,6 +83,30 @@ struct Carver {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
+// XCD-aware tile order for kernels whose blocks read a halo of their neighbours' pixels.  Workgroups are dealt
+// round-robin over the 8 XCDs (blocks b and b + 8 share one; MI355X_MICROARCH.md, "Workgroup dispatch"), each XCD with
+// an L2 of its own: with the plain blockIdx -> tile map the left / right neighbour of a tile runs on ANOTHER XCD, so
+// every halo column costs its full cache line from HBM a second time (for a 64-column tile of 4-byte pixels: 6 lines
+// fetched per 4 used).  This map hands XCD k the k-th eighth of the tile sequence (x fastest, then y, then frame), in
+// order: neighbouring tiles of a frame are issued together on one XCD and share their halo lines in its L2.  Speed
+// only -- any block -> tile bijection is correct.
+struct TileIndex {
+    int x, y, z;
+};
+__device__ __forceinline__ TileIndex xcd_tile_index()
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    const unsigned b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned per = total / 8u;
+    const unsigned t = b < per * 8u ? (b % 8u) * per + b / 8u : b;  // (a remainder of < 8 blocks keeps its place)
+    TileIndex ti;
+    ti.x = (int)(t % gx);
+    ti.y = (int)((t / gx) % gy);
+    ti.z = (int)(t / (gx * gy));
+    return ti;
+}
+
 // relaxed agent-scope accesses: served by L2, never by a stale L1 line
 __device__ __forceinline__ int ld_agent(const int *p)
 {

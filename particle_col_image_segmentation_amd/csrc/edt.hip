@@ -273,21 +273,34 @@ __global__ void __launch_bounds__(256) edt_reach_kernel(const unsigned *__restri
     const unsigned valid = rows_in_word == 32 ? 0xFFFFFFFFu : ((1u << rows_in_word) - 1u);
     const int nrows = min(EDT_RB, H - r0);
     const int64_t wbase = ((int64_t)b * nch + ch) * W;
+    const int R2 = epi.R2();
+    const unsigned gmax = (unsigned)sqrtf((float)R2) + 1;  // larger distances can never be within reach
+    // rows whose every column is further than that from a zero pixel vertically (most of a frame when the zero set is
+    // one compact object, like the particle of fill_particle_area): nothing is within reach, no scan is needed
+    bool near = false;
     for (int c = threadIdx.x; c < W; c += 256) {
         unsigned word = bits[wbase + c];
         unsigned u = up[wbase + c], d = dn[wbase + c];
 #pragma unroll
         for (int j = 0; j < EDT_RB; ++j)
-            if (j < nrows) g[j * W + c] = (uint16_t)min(vdist(word, valid, j0 + j, u, d, rows_in_word), 0x7FFFu);  // bit 15 stays free
+            if (j < nrows) {
+                const unsigned v = min(vdist(word, valid, j0 + j, u, d, rows_in_word), 0x7FFFu);
+                g[j * W + c] = (uint16_t)v;  // bit 15 stays free
+                near = near || v <= gmax;
+            }
     }
-    __syncthreads();
+    const bool any_near = __syncthreads_or(near);
     const bool anybg = any_bg[b] != 0;
-    const int R2 = epi.R2();
-    const unsigned gmax = (unsigned)sqrtf((float)R2) + 1;  // larger distances can never be within reach
     const int64_t fbase = (int64_t)b * H * W;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int nchunks = (W + WAVE - 1) / WAVE;
     unsigned long long cnt = 0;
+    if (!any_near && anybg) {
+        for (int idx = threadIdx.x; idx < nrows * W; idx += 256) {
+            const int j = idx / W, c = idx % W;
+            epi.store(fbase + (int64_t)(r0 + j) * W + c, false, true, r0 + j, c, cnt);
+        }
+    } else
     for (int j = wave; j < nrows; j += 4) {
         uint16_t *gr = g + j * W;
         int carry = -1;

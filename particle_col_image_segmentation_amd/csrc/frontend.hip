@@ -50,8 +50,9 @@ __global__ void __launch_bounds__(256) classmap_median_ccl_kernel(const float *_
     __shared__ __attribute__((aligned(16))) uint32_t hot[MED_LH * MED_LW];  // 1 << (5 * class) of the tile + halo
     __shared__ int key[CCL_TILE];
     __shared__ int par[CCL_TILE];
-    const int b = blockIdx.z;
-    const int r0 = blockIdx.y * MED_TH, c0 = blockIdx.x * MED_TW;
+    const TileIndex ti = xcd_tile_index();  // the 2-pixel halo is the neighbours' rim: keep them on one XCD's L2
+    const int b = ti.z;
+    const int r0 = ti.y * MED_TH, c0 = ti.x * MED_TW;
     const int64_t n = (int64_t)H * W;
     const float *fr = stack + (int64_t)b * C * n;
     // (1) classes of the 36 x 68 pixels around the tile.  Interior columns of a full-width tile: 16-byte loads

@@ -291,7 +291,8 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
                                                         WsTiling cur, WsTiling nxt, int max_iter)
 {
     __shared__ uint2 sLV[WS_N];
-    ws_relax_tile(sLV, in, FIRST, val, L, dirty_in, dirty_out, any_changed, H, W, cur, nxt, max_iter, blockIdx.x, blockIdx.y, blockIdx.z);
+    const TileIndex t = xcd_tile_index();  // a tile's halo is its neighbours' rim: keep them on one XCD's L2
+    ws_relax_tile(sLV, in, FIRST, val, L, dirty_in, dirty_out, any_changed, H, W, cur, nxt, max_iter, t.x, t.y, t.z);
 }
 
 // The fixed point is driven WITHOUT the host: a fixed number of grid rounds is enqueued (a round whose tiles carry no
@@ -410,13 +411,14 @@ __device__ __forceinline__ void vunite_glb(int *par, int p, int q)
 }
 
 template <typename KeyT>
-__device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM, const int b, const KeyT *__restrict__ K,
+__device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM, const int b, const int tile_x, const int tile_y,
+                                                 const KeyT *__restrict__ K,
                                                  const int *__restrict__ F, const uint8_t *__restrict__ active,
                                                  int *__restrict__ parent, uint8_t *__restrict__ minmask, int H, int W, int tilesX,
                                                  int tilesY)
 {
     const KeyT KINF = ~(KeyT)0;
-    const int r0 = blockIdx.y * UF_TH, c0 = blockIdx.x * UF_TW;
+    const int r0 = tile_y * UF_TH, c0 = tile_x * UF_TW;
     if (!ws_active(active, b, r0, c0, tilesX, tilesY)) return;  // UF tiles (64x32) nest inside the 64x64 tiles
     const int64_t fbase = (int64_t)b * H * W;
     for (int i = threadIdx.x; i < UF_SH * UF_SW; i += 256) {
@@ -513,11 +515,12 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__
     __shared__ int par[UF_TH * UF_TW];
     __shared__ uint8_t sM[UF_LNS];
     if constexpr (!LIST) {
-        ws_uf_tile_frame<KeyT>(sK, par, sM, blockIdx.z, K, F, active, parent, minmask, H, W, tilesX, tilesY);
+        const TileIndex t = xcd_tile_index();
+        ws_uf_tile_frame<KeyT>(sK, par, sM, t.z, t.x, t.y, K, F, active, parent, minmask, H, W, tilesX, tilesY);
     } else {
         const int n = frame_list[-1];
         for (int gi = blockIdx.z; gi < n; gi += gridDim.z) {
-            ws_uf_tile_frame<KeyT>(sK, par, sM, frame_list[gi], K, F, active, parent, minmask, H, W, tilesX, tilesY);
+            ws_uf_tile_frame<KeyT>(sK, par, sM, frame_list[gi], blockIdx.x, blockIdx.y, K, F, active, parent, minmask, H, W, tilesX, tilesY);
             __syncthreads();  // the next listed frame reuses the tile arrays
         }
     }
@@ -1187,7 +1190,7 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
 
 // grid rounds enqueued before the per-frame tail kernels take over (see ws_relax_tail_kernel): the benchmark batch needs
 // 10 relaxation rounds; a round without marks costs a few microseconds
-constexpr int WS_GRID_ROUNDS = 12, WS_K2_GRID_ROUNDS = 6;
+constexpr int WS_GRID_ROUNDS = 12, WS_K2_GRID_ROUNDS = 4;
 
 int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *markers, const uint8_t *mask, int32_t *out,
                          int32_t *tie_flags, int B, int H, int W, int mode, void *workspace, size_t workspace_bytes,

@@ -15,7 +15,7 @@ def shard_frames(n_frames, rank, world_size):
     return list(range(rank, n_frames, world_size))
 
 
-def all_gather_table(table, group=None, sort_cols=(0, 1)):
+def all_gather_table(table, group=None, sort_cols=(0, 1), presorted=False):
     """Gather (rows_r, cols) float64 tables from every rank into one table, sorted by the key columns
     (frame, label) so that the result does not depend on the number of ranks."""
     if not dist.is_available() or not dist.is_initialized():
@@ -33,6 +33,9 @@ def all_gather_table(table, group=None, sort_cols=(0, 1)):
         parts = [torch.zeros_like(pad) for _ in range(world)]
         dist.all_gather(parts, pad, group=group)
         out = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+    single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
+    if presorted and single:
+        return out  # one rank, rows already in (frame, label) order: nothing to merge
     if out.shape[0] and sort_cols:
         key = out[:, sort_cols[0]].to(torch.float64)
         for c in sort_cols[1:]:
@@ -42,50 +45,57 @@ def all_gather_table(table, group=None, sort_cols=(0, 1)):
 
 
 TABLE_KEYS = ("cells", "rois", "frames", "groups", "distances")
+_SORT_COLS = {"frames": (0,), "frames_rec": (0,), "groups": (0, 1, 2)}
 
 
-def gather_tables(tables, device=None, group=None):
-    """all-gather every table of FramePipeline.tables() (numpy in, numpy out).  Every rank must pass the same set of
-    2-D tables with the same column counts -- also a rank without a single row (``(0, ncols)`` arrays)."""
+def gather_tables(tables, device=None, group=None, presorted=False):
+    """all-gather every 2-D table of a dict (numpy arrays or tensors in, same kind out), each sorted by its key columns.
+    Every rank must pass the same set of tables with the same column counts -- also a rank without a single row
+    (``(0, ncols)`` arrays)."""
     out = dict(tables)
-    for name in [k for k in TABLE_KEYS if isinstance(tables.get(k), np.ndarray)]:
-        t = torch.from_numpy(np.ascontiguousarray(tables[name], dtype=np.float64))
+    for name, value in tables.items():
+        is_np = isinstance(value, np.ndarray)
+        if not (is_np or isinstance(value, torch.Tensor)) or value.ndim != 2:
+            continue
+        t = torch.from_numpy(np.ascontiguousarray(value, dtype=np.float64)) if is_np else value
         if device is not None:
             t = t.to(device)
-        sort_cols = (0,) if name == "frames" else ((0, 1, 2) if name == "groups" else (0, 1))
-        out[name] = all_gather_table(t, group, sort_cols).cpu().numpy()
+        g = all_gather_table(t, group, _SORT_COLS.get(name, (0, 1)), presorted and name != "distances")
+        out[name] = g.cpu().numpy() if is_np else g
     return out
 
 
-def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, planes=5, **table_kwargs):
+def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, planes=5, check=True, **table_kwargs):
     """BASELINE configs 3 / 5: frames ``rank, rank + world, ...`` of a dataset go through ``pipe`` in batches of
-    ``batch`` and the per-ROI tables of all ranks are gathered once at the end.  ``make_batch(frame_ids)`` returns the
+    ``batch`` and the tables of all ranks are gathered once at the end.  ``make_batch(frame_ids)`` returns the
     ``(len(frame_ids), planes, H, W)`` float32 CUDA stack of those frames (e.g. ``synth.gen_batch_torch`` per seed, or
-    frames written by ``split_zstack.process_tif``).
+    frames written by ``split_zstack.process_tif`` through ``ingest.FrameUploader``).
 
-    Batch k's tables are taken only after batch k + 1 has been handed to the pipeline, so the table assembly and its
-    download run under the next batch's kernels.  A rank that owns no frame (``n_frames < world``) contributes empty
-    tables of the pipeline's schema (``pipe.table_columns``), so that every rank enters the same collectives with the
-    same column counts."""
+    Per batch only the device-side table assembly runs (``pipe.tables_device``: three kernels and one 24-byte read),
+    and only after the NEXT batch has been handed to the pipeline, so it sits under that batch's kernels.  The per-batch
+    device tables are concatenated, all-gathered as device tensors (RCCL when the group is NCCL) and downloaded ONCE;
+    the host epilogue (``pipe.host_tables``) then runs on the gathered rows.  A rank that owns no frame
+    (``n_frames < world``) contributes ``pipe.empty_device_tables``, so that every rank enters the same collectives with
+    the same column counts.  ``table_kwargs`` (ratios, distances, raster) go to ``host_tables``."""
     rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     mine = shard_frames(n_frames, rank, world)
+    ratio_kw = {"ratios": table_kwargs["ratios"]} if "ratios" in table_kwargs else {}
     parts = []
     pending = None
     for i in range(0, len(mine), batch):
         ids = mine[i:i + batch]
         res = pipe.run(make_batch(ids))
         if pending is not None:
-            parts.append(pipe.tables(pending[0], frame_ids=pending[1], **table_kwargs))
+            parts.append(pipe.tables_device(pending[0], frame_ids=pending[1], check=check, **ratio_kw))
         pending = (res, ids)
     if pending is not None:
-        parts.append(pipe.tables(pending[0], frame_ids=pending[1], **table_kwargs))
-    columns = pipe.table_columns(planes, **({"ratios": table_kwargs["ratios"]} if "ratios" in table_kwargs else {}))
-    merged = {}
-    for k in TABLE_KEYS:
-        rows = [p[k] for p in parts if k in p]
-        merged[k] = np.concatenate(rows) if rows else np.zeros((0, len(columns[k])), np.float64)
-        if merged[k].shape[1] != len(columns[k]):
-            raise ValueError("table %r has %d columns, the schema says %d" % (k, merged[k].shape[1], len(columns[k])))
-        merged[k + "_columns"] = columns[k]
-    return gather_tables(merged, device=device, group=group)
+        parts.append(pipe.tables_device(pending[0], frame_ids=pending[1], check=check, **ratio_kw))
+    if parts:
+        merged = {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
+    else:
+        merged = pipe.empty_device_tables(planes, device=device, **ratio_kw)
+    # (a rank's own rows come out of the batches in frame order, labels ascending: with one rank that IS the gathered
+    # order and the sort is skipped)
+    gathered = gather_tables(merged, device=device, group=group, presorted=world == 1 and mine == sorted(mine))
+    return pipe.host_tables(gathered, planes, **table_kwargs)

@@ -129,6 +129,26 @@ def _lanes_for(device, lanes):
     return _LANES[key]
 
 
+def _download(tables):
+    """device tensors -> numpy through PINNED staging buffers (torch caches them): all copies are enqueued, then one
+    wait.  A pageable ``.cpu()`` of the ~100 MB ROI table of a dataset costs more than the kernels of a batch."""
+    out, staged = {}, []
+    for k, v in tables.items():
+        if isinstance(v, torch.Tensor) and v.is_cuda:
+            buf = torch.empty(tuple(v.shape), dtype=v.dtype, pin_memory=True)
+            buf.copy_(v, non_blocking=True)
+            staged.append((k, buf))
+        elif isinstance(v, torch.Tensor):
+            out[k] = v.numpy()
+        else:
+            out[k] = np.asarray(v)
+    if staged:
+        torch.cuda.current_stream().synchronize()
+        for k, buf in staged:
+            out[k] = buf.numpy()
+    return out
+
+
 def _on(stream, *tensors):
     """Tensors made on another stream are about to be read by kernels on ``stream``: tell the caching allocator, so
     that freeing them cannot hand their memory to new work of the producing stream while ``stream`` still reads."""
@@ -320,9 +340,9 @@ class FramePipeline:
 
     def tables_device(self, res, frame_ids=None, ratios=RATIOS_5, check=True):
         """The batch as dense row tables, assembled ON THE DEVICE (``csrc/tables.hip``): float64 CUDA tensors ``rois``,
-        ``cells``, ``groups`` and the int64 ``frames`` record (see ``pcseg_table_write`` in include/pcseg.h).  One small
-        device-to-host copy (three row totals) sizes the outputs; nothing else leaves the GPU, so the ROI table can go
-        straight into the all-gather."""
+        ``cells``, ``groups`` and ``frames_rec`` (one row per frame: frame id + the int64 record of
+        ``pcseg_table_write``, see include/pcseg.h).  One small device-to-host copy (three row totals) sizes the
+        outputs; nothing else leaves the GPU, so the tables can go straight into the all-gather."""
         if check:
             res.check()
         else:
@@ -334,48 +354,54 @@ class FramePipeline:
         else:
             fid = torch.as_tensor(list(frame_ids), dtype=torch.int64).to(dev)
         groups = (res.get("groups") or {}) if self.merged else {}
-        return ops.build_tables(res, groups, fid, C, ratios)
+        dt = ops.build_tables(res, groups, fid, C, ratios)
+        dt["frames_rec"] = torch.cat([fid[:, None].to(torch.float64), dt.pop("frames").to(torch.float64)], dim=1)
+        del dt["frame_ids"]
+        return dt
 
-    def tables(self, res, frame_ids=None, ratios=RATIOS_5, distances=False, raster=19.0, check=True):
-        """Download one batch as numpy tables: ``cells`` (one row per cell / cluster region), ``rois`` (one row per
-        refined ROI), ``frames`` (one row per frame) and ``groups`` (one row per merged group).  The rows are built by
-        :meth:`tables_device`; the host only applies the two ``round(x, 5)`` of get_cell_counts_and_densities
-        (tiff_analysis.py:1018-1038; Python's decimal rounding) to B x n_types numbers.  ``check=False`` skips
-        ``BatchResult.check`` (a caller that has looked at the flags itself, e.g. to keep the ROI rows of a batch in
-        which the reference would have raised on one frame's cluster statistics)."""
-        B, C, H, W = res["shape"]
-        dt = self.tables_device(res, frame_ids, ratios, check)
+    def empty_device_tables(self, C, ratios=RATIOS_5, device=None):
+        """What :meth:`tables_device` returns for zero frames (a rank that owns no frame of a dataset)."""
+        cols = self.table_columns(C, ratios)
+        mk = lambda n: torch.zeros((0, n), dtype=torch.float64, device=device)
+        return {"rois": mk(len(cols["rois"])), "cells": mk(len(cols["cells"])), "groups": mk(len(cols["groups"])),
+                "frames_rec": mk(18)}
+
+    def host_tables(self, dt, C, ratios=RATIOS_5, distances=False, raster=19.0):
+        """numpy tables from (downloaded or gathered) :meth:`tables_device` output: ``cells`` / ``rois`` / ``groups`` as
+        they are, ``frames`` after the two ``round(x, 5)`` of get_cell_counts_and_densities (tiff_analysis.py:1018-1038;
+        Python's decimal rounding, a handful of numbers per frame), ``distances`` on request (.m:260-268)."""
+        host = _download(dt)
         cols = self.table_columns(C, ratios)
         tb = self.tables_
-        out = {k: dt[k].cpu().numpy() for k in ("cells", "rois", "groups")}
-        rec = dt["frames"].cpu().numpy()
-        fid = dt["frame_ids"].cpu().numpy()
+        out = {k: host[k] for k in ("cells", "rois", "groups")}
+        rec = host["frames_rec"]
         px2 = ta.PX_TO_UM_CONV ** 2
         frame_rows = []
-        for b in range(B):
-            row = [float(fid[b])] + [float(v) for v in rec[b, :5]]
-            pa_um = float(rec[b, 2]) / px2
+        for row_rec in rec:
+            row = [float(v) for v in row_rec[:6]]
+            pa_um = float(row_rec[3]) / px2
             for s in range(len(tb.slot_names)):
-                present, count, area_px = (int(v) for v in rec[b, 5 + 3 * s: 8 + 3 * s])
+                present, count, area_px = (int(v) for v in row_rec[6 + 3 * s: 9 + 3 * s])
                 dens = round(count / pa_um, 5) if present and pa_um else float("nan")
                 ratio = round((area_px / px2) / pa_um, 5) if present and pa_um else float("nan")
                 row += [float(present), float(count), dens, ratio]
             frame_rows.append(row)
-        out["frames"] = np.array(frame_rows, np.float64).reshape(B, len(cols["frames"]))
+        out["frames"] = np.array(frame_rows, np.float64).reshape(len(frame_rows), len(cols["frames"]))
         dist_rows = []
-        if distances:
+        if distances and torch.cuda.is_available():
             # .m:260-268 per frame: nearest ROI of the other cell type for the cells / clusters of slots 0 and 1
             cells = out["cells"]
             slot = tb.slot[cells[:, 2].astype(np.int64)] if len(cells) else np.zeros(0, np.uint8)
-            for f in fid:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            for f in rec[:, 0]:
                 rows = cells[:, 0] == f
                 pos = {}
                 for s in (0, 1):
                     sel = cells[rows & (slot == s)]
                     pos[s] = (sel[:, 1], np.stack([sel[:, 6] + 1.0, sel[:, 5] + 1.0], axis=1))
                 if len(pos[0][0]) and len(pos[1][0]):
-                    ta_ = torch.from_numpy(np.ascontiguousarray(pos[0][1])).to(dt["rois"].device)
-                    tc_ = torch.from_numpy(np.ascontiguousarray(pos[1][1])).to(dt["rois"].device)
+                    ta_ = torch.from_numpy(np.ascontiguousarray(pos[0][1])).to(dev)
+                    tc_ = torch.from_numpy(np.ascontiguousarray(pos[1][1])).to(dev)
                     da, dc = ops.nearest_dist(ta_, tc_).cpu().numpy(), ops.nearest_dist(tc_, ta_).cpu().numpy()
                     for lab, d in list(zip(pos[0][0], da)) + list(zip(pos[1][0], dc)):
                         dist_rows.append([f, lab, d / (512.0 / raster)])
@@ -383,3 +409,12 @@ class FramePipeline:
         for k, v in cols.items():
             out[k + "_columns"] = v
         return out
+
+    def tables(self, res, frame_ids=None, ratios=RATIOS_5, distances=False, raster=19.0, check=True):
+        """Download one batch as numpy tables: ``cells`` (one row per cell / cluster region), ``rois`` (one row per
+        refined ROI), ``frames`` (one row per frame) and ``groups`` (one row per merged group): :meth:`tables_device`
+        followed by :meth:`host_tables`.  ``check=False`` skips ``BatchResult.check`` (a caller that has looked at the
+        flags itself, e.g. to keep the ROI rows of a batch in which the reference would have raised on one frame's
+        cluster statistics)."""
+        C = res["shape"][1]
+        return self.host_tables(self.tables_device(res, frame_ids, ratios, check), C, ratios, distances, raster)

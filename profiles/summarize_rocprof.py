@@ -34,7 +34,7 @@ def short(name):
 def main(src, tag, here=None):
     here = here or os.path.dirname(os.path.abspath(__file__))
     os.makedirs(here, exist_ok=True)
-    trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
+    trace = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True))[0]
     dur = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
         if "pcseg::" in r["Kernel_Name"]:
@@ -48,7 +48,7 @@ def main(src, tag, here=None):
                         round(100 * sum(v) / total, 2)])
     pmc = {}
     for sub, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+        files = sorted(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True))
         if not files:
             continue
         agg = collections.defaultdict(lambda: [0, 0.0])
@@ -83,6 +83,18 @@ def main(src, tag, here=None):
                     best[base] = (fc, int((2 * (fv / fc if fc else 0) + (wv / wc if wc else 0)) * 1024))
             traffic = {k: v[1] for k, v in best.items()}
         json.dump(traffic, open(os.path.join(here, "traffic.json"), "w"), indent=1, sort_keys=True)
+        # whole chain per step: every kernel's launches x bytes; the number of steps in the PMC run = launches of the
+        # front-end kernel (one per step)
+        steps = 0
+        for k in names:
+            if k.startswith("classmap_median_ccl_kernel") or k.startswith("argmax_kernel"):
+                steps = max(steps, pmc.get("FETCH_SIZE", {}).get(k, [0, 0.0])[0])
+        if steps:
+            fetch = sum(v[1] for v in pmc.get("FETCH_SIZE", {}).values()) * 1024 * 2 / steps
+            write = sum(v[1] for v in pmc.get("WRITE_SIZE", {}).values()) * 1024 / steps
+            json.dump({"steps_in_pmc_run": steps, "fetch_bytes_per_step_corrected": int(fetch), "write_bytes_per_step": int(write),
+                       "hbm_bytes_per_step": int(fetch + write)},
+                      open(os.path.join(here, "%s_chain_traffic.json" % tag), "w"), indent=1)
     print("wrote", tag, "summaries:", len(dur), "kernels,", len(traffic), "traffic entries")
 
 

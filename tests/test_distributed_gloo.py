@@ -25,7 +25,8 @@ def _fixture():
 
 
 class _ReplayPipe:
-    """FramePipeline's table interface over the stored per-frame rows."""
+    """FramePipeline's table interface (tables_device / empty_device_tables / host_tables) over the stored per-frame
+    rows: ``tables_device`` hands out the fixture's rows of the frames it is asked for as CPU tensors."""
 
     def __init__(self):
         self.fix = _fixture()
@@ -33,15 +34,21 @@ class _ReplayPipe:
     def run(self, ids):
         return list(ids)
 
-    def table_columns(self, planes, ratios=None):
-        return {k: [str(c) for c in self.fix[k + "_columns"]] for k in TABLE_KEYS}
-
-    def tables(self, res, frame_ids=None):
+    def tables_device(self, res, frame_ids=None, check=True):
         assert list(res) == list(frame_ids)
         out = {}
         for k in TABLE_KEYS:
             t = self.fix[k]
-            out[k] = np.concatenate([t[t[:, 0] == f] for f in frame_ids]) if len(frame_ids) else t[:0]
+            rows = np.concatenate([t[t[:, 0] == f] for f in frame_ids]) if len(frame_ids) else t[:0]
+            out[k] = torch.from_numpy(np.ascontiguousarray(rows))
+        return out
+
+    def empty_device_tables(self, planes, device=None):
+        return {k: torch.zeros((0, self.fix[k].shape[1]), dtype=torch.float64) for k in TABLE_KEYS}
+
+    def host_tables(self, dt, planes):
+        out = {k: dt[k].numpy() for k in TABLE_KEYS}
+        for k in TABLE_KEYS:
             out[k + "_columns"] = [str(c) for c in self.fix[k + "_columns"]]
         return out
 
