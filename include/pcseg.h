@@ -268,7 +268,8 @@ int pcseg_remove_overlapping(const uint8_t *dapi, const uint8_t *other, double t
  *   frames int64 (B, 17)           n_labels, n_rois, particle_area, particle_area + overlap, tie_flag, then per
  *                                  cell-type slot: present, count, area in pixels (tiff_analysis.py:1018-1038
  *                                  before its two round(x, 5), which the host applies)
- * pcseg_table_layout counts and scans (totals: device int64[3] = rows of rois, cells, groups); the caller reads the
+ * pcseg_table_layout counts and scans (totals: device int64[6] = rows of rois, cells, groups, then the number of frames
+ * with overflow / ws_overflow / nan_flag set, so that one read-back serves the caller's checks too); the caller reads the
  * totals, allocates, and pcseg_table_write fills the tables.  Both asynchronous on `stream`; every pointer of the
  * struct is a device pointer, group_of / n_groups / group_stats entries may be NULL (slot absent / merged = False). */
 typedef struct pcseg_table_inputs {
@@ -281,6 +282,7 @@ typedef struct pcseg_table_inputs {
     const int32_t *group_of[5]; const int32_t *n_groups[5]; const int64_t *group_stats[5];       /* (B, cap), (B), (B, cap, 8) */
     const int32_t *n_markers; const int64_t *ws_stats; const double *ws_sums;                     /* refined ROIs */
     int32_t ratio_num[8]; int32_t ratio_den[8][4];              /* plane indices, -1 = unused */
+    const int32_t *overflow; const int32_t *ws_overflow; const int32_t *nan_flag;  /* per-frame flags (B), may be NULL */
 } pcseg_table_inputs;
 size_t pcseg_table_workspace_bytes(int B, int cap);
 int pcseg_table_layout(const pcseg_table_inputs *in, int64_t *totals, void *workspace, size_t workspace_bytes,

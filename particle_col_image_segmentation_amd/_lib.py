@@ -81,7 +81,8 @@ class TableInputs(ctypes.Structure):
                 ("region_list", _P), ("n_list", _P),
                 ("group_of", _P * 5), ("n_groups", _P * 5), ("group_stats", _P * 5),
                 ("n_markers", _P), ("ws_stats", _P), ("ws_sums", _P),
-                ("ratio_num", ctypes.c_int32 * 8), ("ratio_den", (ctypes.c_int32 * 4) * 8)]
+                ("ratio_num", ctypes.c_int32 * 8), ("ratio_den", (ctypes.c_int32 * 4) * 8),
+                ("overflow", _P), ("ws_overflow", _P), ("nan_flag", _P)]
 
 
 def load():

@@ -27,7 +27,8 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + os.environ.get("PCSEG_EXTRA_FLAGS", "").split() + [
+            "-c", os.path.join(CSRC, src), "-o", obj]  # PCSEG_EXTRA_FLAGS: -D tunables for A/B builds (profiles/ab_compare.sh)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -648,14 +648,28 @@ __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__res
     __shared__ int tile[LM_SH * LM_SW];
     __shared__ uint8_t cand[LM_CH * LM_CW];  // tile + 1 ring: 0 inside and not a candidate, 1 candidate, 2 outside the image
     __shared__ int key[CCL_TILE];
-    __shared__ int par[CCL_TILE];
+    static_assert(LM_SH * LM_SW >= CCL_TILE, "the parents reuse the value tile");
+    int *par = tile;  // the values are dead once the keys are out (20 KB per block instead of 28: 8 blocks per CU)
     const int OUTSIDE = (int)0x80000000;  // image values are > INT_MIN by contract: never higher, never "different"
     const TileIndex ti = xcd_tile_index();
     const int r0 = ti.y * LM_TH, c0 = ti.x * LM_TW;
     const int64_t fbase = (int64_t)ti.z * H * W;
-    for (int i = threadIdx.x; i < LM_SH * LM_SW; i += 256) {
-        int r = r0 + i / LM_SW - 2, c = c0 + i % LM_SW - 2;
-        tile[i] = (r >= 0 && r < H && c >= 0 && c < W) ? img[fbase + (int64_t)r * W + c] : OUTSIDE;
+    {
+        // one batch of loads instead of a loop of round trips (clamped addresses, no branch around the loads)
+        constexpr int TRIPS = (LM_SH * LM_SW + 255) / 256;
+        int tv[TRIPS];
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = min((int)threadIdx.x + 256 * t, LM_SH * LM_SW - 1);
+            const int r = r0 + i / LM_SW - 2, c = c0 + i % LM_SW - 2;
+            tv[t] = img[fbase + (int64_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)];
+        }
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = (int)threadIdx.x + 256 * t;
+            const int r = r0 + i / LM_SW - 2, c = c0 + i % LM_SW - 2;
+            if (i < LM_SH * LM_SW) tile[i] = (r >= 0 && r < H && c >= 0 && c < W) ? tv[t] : OUTSIDE;
+        }
     }
     __syncthreads();
     bool any_differs = false;

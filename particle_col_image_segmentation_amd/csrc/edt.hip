@@ -21,7 +21,10 @@ constexpr unsigned G_INF = 0xFFFFu;  // "no zero pixel in this column"
 struct FgNzU8 {
     static constexpr bool kBytes = true;  // one input byte per pixel, no side output: eligible for 4-column loads
     const uint8_t *p;
+    typedef uint8_t raw_t;
     __device__ __forceinline__ bool byte(unsigned v) const { return v != 0; }
+    __device__ __forceinline__ raw_t raw(int b, int64_t pix, int64_t n) const { return p[b * n + pix]; }
+    __device__ __forceinline__ bool from_raw(raw_t v, int, int64_t, int64_t) const { return v != 0; }
     __device__ __forceinline__ bool operator()(int b, int64_t pix, int64_t n) const { return p[b * n + pix] != 0; }
 };
 struct FgLtF32 {
@@ -30,18 +33,26 @@ struct FgLtF32 {
     float thr;
     uint8_t *mask_out;
     int64_t frame_stride;  // elements between frames of p (a plane inside a (B,C,H,W) stack)
-    __device__ __forceinline__ bool operator()(int b, int64_t pix, int64_t n) const
+    typedef float raw_t;
+    // load and test are separate so that a thread can issue all the loads of its word before the first side store
+    // (a byte store may alias anything: the compiler will not move a later load above it)
+    __device__ __forceinline__ raw_t raw(int b, int64_t pix, int64_t) const { return p[b * frame_stride + pix]; }
+    __device__ __forceinline__ bool from_raw(raw_t v, int b, int64_t pix, int64_t n) const
     {
-        bool m = p[b * frame_stride + pix] < thr;
+        const bool m = v < thr;
         if (mask_out) mask_out[b * n + pix] = m;
         return m;
     }
+    __device__ __forceinline__ bool operator()(int b, int64_t pix, int64_t n) const { return from_raw(raw(b, pix, n), b, pix, n); }
 };
 struct FgNotInSetU8 {
     static constexpr bool kBytes = true;
     const uint8_t *p;
     unsigned long long bits;
+    typedef uint8_t raw_t;
     __device__ __forceinline__ bool byte(unsigned v) const { return !(v < 64 && ((bits >> v) & 1ull)); }
+    __device__ __forceinline__ raw_t raw(int b, int64_t pix, int64_t n) const { return p[b * n + pix]; }
+    __device__ __forceinline__ bool from_raw(raw_t v, int, int64_t, int64_t) const { return byte(v); }
     __device__ __forceinline__ bool operator()(int b, int64_t pix, int64_t n) const { return byte(p[b * n + pix]); }
 };
 
@@ -55,10 +66,19 @@ __global__ void __launch_bounds__(256) edt_bits_kernel(Fg fg, unsigned *__restri
     const int64_t n = (int64_t)H * W;
     const int r0 = ch * EDT_CH;
     unsigned word = 0;
+    if (r0 + EDT_CH <= H) {  // full word: no row test around the loads, all 32 of them in flight together
+        typename Fg::raw_t raw[EDT_CH];
+#pragma unroll
+        for (int j = 0; j < EDT_CH; ++j) raw[j] = fg.raw(b, (int64_t)(r0 + j) * W + c, n);
+#pragma unroll
+        for (int j = 0; j < EDT_CH; ++j)
+            if (fg.from_raw(raw[j], b, (int64_t)(r0 + j) * W + c, n)) word |= 1u << j;
+    } else {
 #pragma unroll 8
-    for (int j = 0; j < EDT_CH; ++j) {
-        int r = r0 + j;
-        if (r < H && fg(b, (int64_t)r * W + c, n)) word |= 1u << j;
+        for (int j = 0; j < EDT_CH; ++j) {
+            int r = r0 + j;
+            if (r < H && fg(b, (int64_t)r * W + c, n)) word |= 1u << j;
+        }
     }
     bits[((int64_t)b * nch + ch) * W + c] = word;
 }
@@ -433,7 +453,13 @@ static int edt_run(Fg fg, Epi epi, unsigned long long *count, int B, int H, int 
         };
         const size_t per_row = (size_t)(W + 2) * sizeof(unsigned);
         int rc;
-        if (8 * per_row <= 64 * 1024) rc = launch_rows(std::integral_constant<int, 8>());
+#ifndef PCSEG_EDT_ROWS
+#define PCSEG_EDT_ROWS 4
+#endif
+        // rows per block: the search is a chain of dependent LDS reads, so occupancy beats amortising the staging --
+        // 4 rows (17 KB at W = 1024, 8+ blocks per CU) measured 20 % faster than 8, 2 rows were tried too
+        if (PCSEG_EDT_ROWS == 8 && 8 * per_row <= 64 * 1024) rc = launch_rows(std::integral_constant<int, 8>());
+        else if (PCSEG_EDT_ROWS == 2 && 2 * per_row <= 160 * 1024) rc = launch_rows(std::integral_constant<int, 2>());
         else if (4 * per_row <= 160 * 1024) rc = launch_rows(std::integral_constant<int, 4>());
         else rc = launch_rows(std::integral_constant<int, 1>());
         if (rc) return rc;

@@ -47,9 +47,12 @@ template <int CT>
 __global__ void __launch_bounds__(256) classmap_median_ccl_kernel(const float *__restrict__ stack, int C, uint8_t *__restrict__ z,
                                                                    int *__restrict__ parent, int H, int W)
 {
+    // the histogram words are dead once the medians are out: the union-find parents take their place (18 KB per block
+    // instead of 26: 8 blocks per CU -- the kernel waits on memory most of the time and wants the waves)
     __shared__ __attribute__((aligned(16))) uint32_t hot[MED_LH * MED_LW];  // 1 << (5 * class) of the tile + halo
     __shared__ int key[CCL_TILE];
-    __shared__ int par[CCL_TILE];
+    static_assert(sizeof(uint32_t) * MED_LH * MED_LW >= sizeof(int) * CCL_TILE, "parents fit the histogram words");
+    int *par = reinterpret_cast<int *>(hot);
     const TileIndex ti = xcd_tile_index();  // the 2-pixel halo is the neighbours' rim: keep them on one XCD's L2
     const int b = ti.z;
     const int r0 = ti.y * MED_TH, c0 = ti.x * MED_TW;
@@ -58,16 +61,30 @@ __global__ void __launch_bounds__(256) classmap_median_ccl_kernel(const float *_
     // (1) classes of the 36 x 68 pixels around the tile.  Interior columns of a full-width tile: 16-byte loads
     const bool wide = c0 + MED_TW <= W && (W & 3) == 0 && ((uintptr_t)stack & 15) == 0;
     if (wide) {
-        for (int i = threadIdx.x; i < MED_LH * (MED_TW / 4); i += 256) {
+        // (unrolled, branch-free row reflection for H >= 2: the loads of all trips are issued as one batch)
+        constexpr int QUADS = MED_LH * (MED_TW / 4), TRIPS = (QUADS + 255) / 256;
+        unsigned cls4[TRIPS];
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = min((int)threadIdx.x + 256 * t, QUADS - 1);
             const int lr = i / (MED_TW / 4), q = i % (MED_TW / 4);
             int rr = r0 + lr - 2;
-            if (rr < 0 || rr >= H) rr = reflect_idx(rr, H);  // only tiles on the frame's rim pay for the modulo
-            const unsigned a = classes4<CT>(fr, C, n, (int64_t)rr * W + c0 + 4 * q);
-            uint32_t *dst = hot + lr * MED_LW + 2 + 4 * q;
-            dst[0] = 1u << (5 * (a & 255u));
-            dst[1] = 1u << (5 * ((a >> 8) & 255u));
-            dst[2] = 1u << (5 * ((a >> 16) & 255u));
-            dst[3] = 1u << (5 * (a >> 24));
+            rr = H >= 4 ? (rr < 0 ? -1 - rr : (rr >= H ? 2 * H - 1 - rr : rr)) : reflect_idx(rr, H);
+            rr = min(max(rr, 0), H - 1);  // (rows of a ragged last tile far below the frame: any valid row, unused)
+            cls4[t] = classes4<CT>(fr, C, n, (int64_t)rr * W + c0 + 4 * q);
+        }
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = (int)threadIdx.x + 256 * t;
+            if (i < QUADS) {
+                const int lr = i / (MED_TW / 4), q = i % (MED_TW / 4);
+                const unsigned a = cls4[t];
+                uint32_t *dst = hot + lr * MED_LW + 2 + 4 * q;
+                dst[0] = 1u << (5 * (a & 255u));
+                dst[1] = 1u << (5 * ((a >> 8) & 255u));
+                dst[2] = 1u << (5 * ((a >> 16) & 255u));
+                dst[3] = 1u << (5 * (a >> 24));
+            }
         }
         for (int i = threadIdx.x; i < MED_LH * 4; i += 256) {  // the two halo columns either side
             const int lr = i >> 2, k = i & 3, lc = k < 2 ? k : MED_TW + k;

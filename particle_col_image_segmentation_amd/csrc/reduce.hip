@@ -204,10 +204,16 @@ __device__ __forceinline__ void region_commit(const RegionSlots &ls, long long *
 // Column-run variant (W % 4 == 0): a lane owns 4 adjacent columns and walks DOWN COL_ROWS rows; it accumulates the
 // vertical run of equal labels in registers (area, row sum, plane sums in float64) and commits when the label
 // changes.  No cross-lane traffic at all; loads are int4 / float4 and coalesced along the row.
-constexpr int COL_ROWS = 32;
+#ifndef PCSEG_COL_ROWS
+#define PCSEG_COL_ROWS 32
+#endif
+constexpr int COL_ROWS = PCSEG_COL_ROWS;
 
+#ifndef PCSEG_RED_WAVES
+#define PCSEG_RED_WAVES 2
+#endif
 template <int NC>
-__global__ void __launch_bounds__(256) region_reduce_col_kernel(const int *__restrict__ labels, const float *__restrict__ planes,
+__global__ void __launch_bounds__(256, PCSEG_RED_WAVES) region_reduce_col_kernel(const int *__restrict__ labels, const float *__restrict__ planes,
                                                                  const uint8_t *__restrict__ cls, unsigned long long sel, int C,
                                                                  int H, int W, int cap, long long *__restrict__ stats,
                                                                  double *__restrict__ sums, int *__restrict__ overflow)

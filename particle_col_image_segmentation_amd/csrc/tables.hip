@@ -57,18 +57,26 @@ __global__ void __launch_bounds__(256) table_count_kernel(pcseg_table_inputs in,
     }
 }
 
-// offsets[b] = exclusive prefix over the frames; totals[3]
-__global__ void __launch_bounds__(64) table_scan_kernel(const long long *__restrict__ counts, long long *__restrict__ offsets,
-                                                         long long *__restrict__ totals, int B)
+// offsets[b] = exclusive prefix over the frames; totals[0..2] = rows of rois / cells / groups, totals[3..5] = number of
+// frames whose region table overflowed (class components, refined ROIs) and of frames on which the reference raises
+// int(NaN): the caller's checks ride on the one read-back that sizes the tables
+__global__ void __launch_bounds__(64) table_scan_kernel(pcseg_table_inputs in, const long long *__restrict__ counts,
+                                                         long long *__restrict__ offsets, long long *__restrict__ totals, int B)
 {
     const int t = threadIdx.x;
-    if (t >= 3) return;
-    long long acc = 0;
-    for (int b = 0; b < B; ++b) {
-        offsets[b * 3 + t] = acc;
-        acc += counts[b * 3 + t];
+    if (t < 3) {
+        long long acc = 0;
+        for (int b = 0; b < B; ++b) {
+            offsets[b * 3 + t] = acc;
+            acc += counts[b * 3 + t];
+        }
+        totals[t] = acc;
+    } else if (t < 6) {
+        const int32_t *flag = t == 3 ? in.overflow : (t == 4 ? in.ws_overflow : in.nan_flag);
+        long long acc = 0;
+        for (int b = 0; flag && b < B; ++b) acc += flag[b] != 0;
+        totals[t] = acc;
     }
-    totals[t] = acc;
 }
 
 __device__ __forceinline__ void tb_ratios(const pcseg_table_inputs &in, const double *s, double *row)
@@ -238,7 +246,7 @@ int pcseg_table_layout(const pcseg_table_inputs *in, int64_t *totals, void *work
     hipStream_t s = (hipStream_t)stream;
     PCSEG_LAUNCH(table_count_kernel, dim3(in->B), dim3(256), 0, s, *in, counts);
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(table_scan_kernel, dim3(1), dim3(64), 0, s, (const long long *)counts, offsets, (long long *)totals, in->B);
+    PCSEG_LAUNCH(table_scan_kernel, dim3(1), dim3(64), 0, s, *in, (const long long *)counts, offsets, (long long *)totals, in->B);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

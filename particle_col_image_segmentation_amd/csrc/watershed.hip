@@ -177,6 +177,7 @@ struct WsInputs {
     const int *markers;
     const uint8_t *mask;
     int *out;
+    bool vec;  // W % 4 == 0 and every array 16-byte aligned per frame: the tile load / store use 16-byte accesses
 };
 
 //
@@ -219,6 +220,94 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
         const unsigned v = ws_key(in.img[(int64_t)b * in.frame_stride + (int64_t)r * W + c]);
         return make_uint2(in.markers[g] != 0 ? v : WS_INF, v);
     };
+    if (in.vec) {
+        // The tile load is ONE batch of loads per thread, not a loop of dependent round trips: every access goes to a
+        // clamped (always valid) address without a branch, so that the unrolled loop is a single basic block whose
+        // loads the compiler issues back to back, and the out-of-frame cells are fixed up by a select afterwards.
+        // Interior columns as 16-byte quads (66 rows x 16 quads over 256 threads: 5 trips), the two halo columns as one
+        // scalar trip.  (A loop with an `if (inside)` around each load measured one full memory latency per trip:
+        // 17 trips, i.e. most of a revisited tile's time.)
+        constexpr int QUADS = WS_S * (WS_T / 4), TRIPS = (QUADS + 255) / 256;
+        const float *img_f = in.img + (int64_t)b * in.frame_stride;
+        const bool halo_thread = threadIdx.x < 2 * WS_S;
+        const int h_lr = threadIdx.x >> 1, h_lc = (threadIdx.x & 1) ? WS_S - 1 : 0;
+        const int h_r = r0 + h_lr - 1, h_c = c0 + h_lc - 1;
+        const bool h_in = halo_thread && h_r >= 0 && h_r < H && h_c >= 0 && h_c < W;
+        const int64_t h_p = (int64_t)min(max(h_r, 0), H - 1) * W + min(max(h_c, 0), W - 1);
+        if (FIRST) {
+            float4 f4[TRIPS];
+            int4 m4[TRIPS];
+            unsigned k4[TRIPS];
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                const int idx = min((int)threadIdx.x + 256 * t, QUADS - 1);
+                const int lr = idx >> 4, q = idx & 15;
+                const int64_t p = (int64_t)min(max(r0 + lr - 1, 0), H - 1) * W + min(max(c0 + 4 * q, 0), W - 4);
+                f4[t] = *reinterpret_cast<const float4 *>(img_f + p);
+                m4[t] = *reinterpret_cast<const int4 *>(in.markers + fbase + p);
+                k4[t] = *reinterpret_cast<const unsigned *>(in.mask + fbase + p);
+            }
+            const float hf = img_f[h_p];
+            const int hm = in.markers[fbase + h_p];
+            const uint8_t hk = in.mask[fbase + h_p];
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                const int idx = (int)threadIdx.x + 256 * t;
+                if (idx < QUADS) {
+                    const int lr = idx >> 4, q = idx & 15;
+                    const int r = r0 + lr - 1, c = c0 + 4 * q;
+                    const bool inside = r >= 0 && r < H && c >= 0 && c < W;
+                    const float fv[4] = {f4[t].x, f4[t].y, f4[t].z, f4[t].w};
+                    const int mv[4] = {m4[t].x, m4[t].y, m4[t].z, m4[t].w};
+                    unsigned key[4];
+                    int lab[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool msk = inside && ((k4[t] >> (8 * j)) & 255u) != 0;
+                        key[j] = msk ? ws_key(fv[j]) : WS_INF;
+                        lab[j] = msk ? mv[j] : 0;
+                        sLV[lr * WS_P + 1 + 4 * q + j] = make_uint2(lab[j] != 0 ? key[j] : WS_INF, key[j]);
+                    }
+                    if (inside && lr >= 1 && lr <= WS_T) {  // own pixels: publish value keys and seed labels
+                        const int64_t g = fbase + (int64_t)r * W + c;
+                        *reinterpret_cast<uint4 *>(val + g) = make_uint4(key[0], key[1], key[2], key[3]);
+                        *reinterpret_cast<int4 *>(in.out + g) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+                    }
+                }
+            }
+            if (halo_thread) {
+                const bool msk = h_in && hk != 0;
+                const unsigned key = msk ? ws_key(hf) : WS_INF;
+                sLV[h_lr * WS_P + h_lc] = make_uint2(msk && hm != 0 ? key : WS_INF, key);
+            }
+        } else {
+            uint4 l4[TRIPS], v4[TRIPS];
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                const int idx = min((int)threadIdx.x + 256 * t, QUADS - 1);
+                const int lr = idx >> 4, q = idx & 15;
+                const int64_t p = fbase + (int64_t)min(max(r0 + lr - 1, 0), H - 1) * W + min(max(c0 + 4 * q, 0), W - 4);
+                l4[t] = *reinterpret_cast<const uint4 *>(L + p);
+                v4[t] = *reinterpret_cast<const uint4 *>(val + p);
+            }
+            const unsigned hl = L[fbase + h_p], hv = val[fbase + h_p];
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                const int idx = (int)threadIdx.x + 256 * t;
+                if (idx < QUADS) {
+                    const int lr = idx >> 4, q = idx & 15;
+                    const int r = r0 + lr - 1, c = c0 + 4 * q;
+                    const bool inside = r >= 0 && r < H && c >= 0 && c < W;
+                    uint2 *dst = sLV + lr * WS_P + 1 + 4 * q;
+                    dst[0] = inside ? make_uint2(l4[t].x, v4[t].x) : make_uint2(WS_INF, WS_INF);
+                    dst[1] = inside ? make_uint2(l4[t].y, v4[t].y) : make_uint2(WS_INF, WS_INF);
+                    dst[2] = inside ? make_uint2(l4[t].z, v4[t].z) : make_uint2(WS_INF, WS_INF);
+                    dst[3] = inside ? make_uint2(l4[t].w, v4[t].w) : make_uint2(WS_INF, WS_INF);
+                }
+            }
+            if (halo_thread) sLV[h_lr * WS_P + h_lc] = h_in ? make_uint2(hl, hv) : make_uint2(WS_INF, WS_INF);
+        }
+    } else
     for (int i = threadIdx.x; i < WS_S * WS_S; i += 256) {
         int lr = i / WS_S, lc = i % WS_S;
         int r = r0 + lr - 1, c = c0 + lc - 1;
@@ -278,6 +367,17 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
         }
     }
     __syncthreads();
+    if (in.vec) {
+#pragma unroll
+        for (int t = 0; t < WS_T * (WS_T / 4) / 256; ++t) {
+            const int idx = threadIdx.x + 256 * t, lr = idx >> 4, q = idx & 15;
+            const int r = r0 + lr, c = c0 + 4 * q;
+            const uint2 *src = sLV + (lr + 1) * WS_P + 1 + 4 * q;
+            if (r >= 0 && r < H && c >= 0 && c < W)
+                *reinterpret_cast<uint4 *>(L + fbase + (int64_t)r * W + c) = make_uint4(src[0].x, src[1].x, src[2].x, src[3].x);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < WS_T * WS_T; i += 256) {
         int lr = i / WS_T, lc = i % WS_T;
         int r = r0 + lr, c = c0 + lc;
@@ -421,15 +521,35 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
     const int r0 = tile_y * UF_TH, c0 = tile_x * UF_TW;
     if (!ws_active(active, b, r0, c0, tilesX, tilesY)) return;  // UF tiles (64x32) nest inside the 64x64 tiles
     const int64_t fbase = (int64_t)b * H * W;
-    for (int i = threadIdx.x; i < UF_SH * UF_SW; i += 256) {
-        int r = r0 + i / UF_SW - 1, c = c0 + i % UF_SW - 1;
-        sK[i] = (r >= 0 && r < H && c >= 0 && c < W) ? K[fbase + (int64_t)r * W + c] : KINF;
+    {
+        // one batch of loads, not a loop of round trips: clamped (always valid) addresses, no branch around the loads,
+        // out-of-frame cells fixed up by a select (see ws_relax_tile)
+        constexpr int TRIPS = (UF_SH * UF_SW + 255) / 256;
+        KeyT kv[TRIPS];
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = min((int)threadIdx.x + 256 * t, UF_SH * UF_SW - 1);
+            const int r = r0 + i / UF_SW - 1, c = c0 + i % UF_SW - 1;
+            kv[t] = K[fbase + (int64_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)];
+        }
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = (int)threadIdx.x + 256 * t;
+            const int r = r0 + i / UF_SW - 1, c = c0 + i % UF_SW - 1;
+            if (i < UF_SH * UF_SW) sK[i] = (r >= 0 && r < H && c >= 0 && c < W) ? kv[t] : KINF;
+        }
     }
     __syncthreads();
     // (1) per pixel: own virtual index and which neighbours hold the minimum neighbour key (bit0 up, 1 left, 2 right,
     // 3 down; 0 for seeds / unreachable).  The masks also go to global memory for the border pass, which then needs
     // two bytes per cross-tile pair instead of ten keys.
     int self[UF_LNS / 256];  // -1: unreachable / outside
+    int fv[UF_LNS / 256];    // labels of the thread's pixels, fetched as one batch (clamped address: no branch)
+#pragma unroll
+    for (int k = 0; k < UF_LNS / 256; ++k) {
+        const int t = threadIdx.x + k * 256;
+        fv[k] = F[fbase + (int64_t)min(r0 + t / UF_TW, H - 1) * W + min(c0 + t % UF_TW, W - 1)];
+    }
 #pragma unroll
     for (int k = 0; k < UF_LNS / 256; ++k) {
         const int t = threadIdx.x + k * 256;
@@ -438,7 +558,7 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
         const int i = (lr + 1) * UF_SW + lc + 1;
         int v = -1;
         if ((unsigned)(sK[i] >> (8 * sizeof(KeyT) - 32)) != WS_INF)  // reachable => inside the frame
-            v = F[fbase + (int64_t)r * W + c] != 0 ? t : t + UF_LNS;  // labelled pixels (seeds) order first
+            v = fv[k] != 0 ? t : t + UF_LNS;  // labelled pixels (seeds) order first
         uint8_t m8 = 0;
         if (v >= UF_LNS) {  // seeds take no label from neighbours
             const KeyT ku = sK[i - UF_SW], kl = sK[i - 1], kr = sK[i + 1], kd = sK[i + UF_SW];
@@ -1240,7 +1360,10 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         PCSEG_LAUNCH(ws_set_flags_kernel, dim3((B + 63) / 64), dim3(64), 0, s, flags2, B, 1);
         PCSEG_CHECK_LAUNCH();
     } else {
-        const WsInputs inputs{img, frame_stride, markers, mask, out};
+        const bool vec = (W & 3) == 0 && W >= 4 && (frame_stride & 3) == 0 && (((uintptr_t)img | (uintptr_t)markers | (uintptr_t)out |
+                                                                                 (uintptr_t)val | (uintptr_t)L) & 15) == 0 &&
+                         ((uintptr_t)mask & 3) == 0;
+        const WsInputs inputs{img, frame_stride, markers, mask, out, vec};
         // minimax relaxation over alternating tilings
         const WsTiling tilings[2] = {{0, tilesX, tilesY}, {WS_T / 2, (W + WS_T / 2 + WS_T - 1) / WS_T, (H + WS_T / 2 + WS_T - 1) / WS_T}};
         // both mark buffers start empty (round 0 visits every tile regardless)

@@ -415,7 +415,7 @@ def classify_regions(stats, cls_out, counts, tables):
     return out
 
 
-def build_tables(res, groups, frame_ids, C, ratios):
+def build_tables(res, groups, frame_ids, C, ratios, check=False):
     """csrc/tables.hip: dense row tables of one batch (see FramePipeline.tables_device)."""
     lib = _lib.load()
     B, cap = res["stats"].shape[0], res["stats"].shape[1]
@@ -458,11 +458,19 @@ def build_tables(res, groups, frame_ids, C, ratios):
         ti.ratio_num[k] = int(num)
         for j in range(4):
             ti.ratio_den[k][j] = int(den[j]) if j < len(den) else -1
+    ti.overflow = ptr(res["overflow"], torch.int32, (B,))
+    ti.ws_overflow = ptr(res["ws_overflow"], torch.int32, (B,))
+    ti.nan_flag = ptr(res["nan_flag"], torch.int32, (B,))
     nbytes = lib.pcseg_table_workspace_bytes(B, cap)
     ws = _ws(nbytes, dev)
-    totals = torch.empty((3,), dtype=torch.int64, device=dev)
+    totals = torch.empty((6,), dtype=torch.int64, device=dev)
     _lib.check(lib.pcseg_table_layout(ctypes.byref(ti), _ptr(totals), _ptr(ws), nbytes, _stream()), "table_layout")
-    n_roi, n_cell, n_group = (int(v) for v in totals.cpu())  # the one host read: sizes of the outputs
+    # the one host read: sizes of the outputs, plus the flags BatchResult.check() would otherwise fetch one by one
+    n_roi, n_cell, n_group, n_overflow, n_ws_overflow, n_nan = (int(v) for v in totals.cpu())
+    if check and (n_overflow or n_ws_overflow):
+        raise RuntimeError("region table capacity exceeded: raise FramePipeline(cap=...)")
+    if check and n_nan:
+        raise ValueError("cannot convert float NaN to integer")  # tiff_analysis.py:776-781
     nr = len(ratios)
     # (one spare row each: an empty table still needs a non-null pointer for the library's argument check)
     rois = torch.empty((n_roi + 1, 5 + C + nr), dtype=torch.float64, device=dev)

@@ -170,6 +170,7 @@ class FramePipeline:
         self.overlap = overlap
         self.lanes = max(1, int(lanes))
         self.multi_stream = bool(multi_stream)  # False: the class-map chain (incl. merges and fill) on ONE stream
+        self._table_stream = None
         self._lane_pool = None  # one single-thread executor + stream set per lane, made on first use
         self._lane_streams = None
         self._step = 0
@@ -343,20 +344,29 @@ class FramePipeline:
         ``cells``, ``groups`` and ``frames_rec`` (one row per frame: frame id + the int64 record of
         ``pcseg_table_write``, see include/pcseg.h).  One small device-to-host copy (three row totals) sizes the
         outputs; nothing else leaves the GPU, so the tables can go straight into the all-gather."""
-        if check:
-            res.check()
-        else:
-            res.synchronize()
+        res.synchronize()
         B, C, H, W = res["shape"]
         dev = res["stats"].device
-        if frame_ids is None:
-            fid = torch.arange(B, dtype=torch.int64, device=dev)
-        else:
-            fid = torch.as_tensor(list(frame_ids), dtype=torch.int64).to(dev)
-        groups = (res.get("groups") or {}) if self.merged else {}
-        dt = ops.build_tables(res, groups, fid, C, ratios)
-        dt["frames_rec"] = torch.cat([fid[:, None].to(torch.float64), dt.pop("frames").to(torch.float64)], dim=1)
-        del dt["frame_ids"]
+        # a stream of its own, at high priority: the handful of small kernels here must not queue behind the next
+        # batch's big ones on a saturated GPU
+        if self._table_stream is None or self._table_stream.device != dev:
+            self._table_stream = torch.cuda.Stream(device=dev, priority=-1)
+        ts = self._table_stream
+        ts.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(ts):
+            ids = list(range(B)) if frame_ids is None else [int(v) for v in frame_ids]
+            step = ids[1] - ids[0] if B > 1 else 1
+            if all(ids[k] == ids[0] + k * step for k in range(B)):  # arithmetic progression (shards are): no upload
+                fid = torch.arange(B, dtype=torch.int64, device=dev) * step + ids[0]
+            else:
+                fid = torch.tensor(ids, dtype=torch.int64).to(dev)
+            groups = (res.get("groups") or {}) if self.merged else {}
+            dt = ops.build_tables(res, groups, fid, C, ratios, check=check)  # raises what BatchResult.check() raises
+            dt["frames_rec"] = torch.cat([fid[:, None].to(torch.float64), dt.pop("frames").to(torch.float64)], dim=1)
+            del dt["frame_ids"]
+        torch.cuda.current_stream(dev).wait_stream(ts)
+        for t in dt.values():
+            t.record_stream(torch.cuda.current_stream(dev))
         return dt
 
     def empty_device_tables(self, C, ratios=RATIOS_5, device=None):

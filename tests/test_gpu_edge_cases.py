@@ -91,3 +91,71 @@ def test_pipeline_on_empty_and_uniform_frames():
         assert int(res["particle_area"][b]) == ref["particle_area"]
     tabs = FramePipeline(ct).tables(res)
     assert tabs["cells"].shape[0] == 0
+
+
+def test_watershed_long_winding_path_finishes_in_the_tail_kernel():
+    """The minimax relaxation enqueues a fixed number of grid rounds and leaves the rest to a per-frame tail kernel
+    (no host polling).  A serpentine corridor whose only marker sits at one end needs one round per tile crossing --
+    far more than the grid rounds -- so this result comes out of the tail kernel; a second frame of plain noise rides in
+    the same launch."""
+    import torch
+    from particle_col_image_segmentation_amd import ops
+    H, W = 448, 448
+    rng = np.random.default_rng(7)
+    mask = np.zeros((H, W), bool)
+    img = np.full((H, W), 0.9, np.float32)
+    # corridor: horizontal runs every 8 rows joined alternately at the right / left end
+    rows = list(range(4, H - 4, 8))
+    order = []
+    for k, r in enumerate(rows):
+        cols = range(4, W - 4) if k % 2 == 0 else range(W - 5, 3, -1)
+        order += [(r, c) for c in cols]
+        if k + 1 < len(rows):
+            cend = W - 5 if k % 2 == 0 else 4
+            order += [(rr, cend) for rr in range(r + 1, rows[k + 1])]
+    for i, (r, c) in enumerate(order):
+        mask[r, c] = True
+        img[r, c] = 0.05 + 0.4 * i / len(order)  # strictly increasing along the corridor: tie-free
+    markers = np.zeros((H, W), np.int32)
+    markers[order[0]] = 1
+    markers[order[len(order) // 2]] = 2
+    img2 = rng.random((H, W)).astype(np.float32)
+    mask2 = img2 < 0.8
+    mk2 = np.zeros((H, W), np.int32)
+    for k in range(1, 40):
+        r, c = rng.integers(0, H), rng.integers(0, W)
+        if mask2[r, c]:
+            mk2[r, c] = k
+    imgs = np.stack([img, img2])
+    out, flags = ops.watershed(torch.from_numpy(imgs).cuda(), torch.from_numpy(np.stack([markers, mk2])).cuda(),
+                               torch.from_numpy(np.stack([mask, mask2]).astype(np.uint8)).cuda())
+    np.testing.assert_array_equal(out[0].cpu().numpy(), orc.watershed(img, markers, mask))
+    np.testing.assert_array_equal(out[1].cpu().numpy(), orc.watershed(img2, mk2, mask2))
+    lab = out[0].cpu().numpy()
+    assert lab[order[-1]] == 2 and lab[order[len(order) // 2 - 1]] == 1  # the far end was reached
+
+
+def test_exact_flood_with_more_frames_than_cus():
+    """A call with more frames than CUs runs the heap emulation with the small LDS share (heap levels 0..6 in LDS, the
+    rest in the workspace; several frames per CU) -- the variant the benchmark's quantised leg uses.  300 small frames
+    full of ties, mode 1 (exact flood for every frame), each against the oracle."""
+    import torch
+    from particle_col_image_segmentation_amd import ops
+    rng = np.random.default_rng(11)
+    B, H, W = 300, 40, 56
+    img = (rng.integers(0, 6, (B, H, W)) / 8.0).astype(np.float32)       # six levels: plateaus and equal seeds everywhere
+    mask = rng.random((B, H, W)) < 0.9
+    markers = np.zeros((B, H, W), np.int32)
+    for b in range(B):
+        for k in range(1, 9):
+            markers[b, rng.integers(0, H), rng.integers(0, W)] = k
+    out, flags = ops.watershed(torch.from_numpy(img).cuda(), torch.from_numpy(markers).cuda(),
+                               torch.from_numpy(mask.astype(np.uint8)).cuda(), mode=1)
+    got = out.cpu().numpy()
+    for b in range(B):
+        np.testing.assert_array_equal(got[b], orc.watershed(img[b], markers[b], mask[b]), err_msg="frame %d" % b)
+    # and through the default mode (parallel flood first, exact flood only where it cannot be proven)
+    out0, flags0 = ops.watershed(torch.from_numpy(img).cuda(), torch.from_numpy(markers).cuda(),
+                                 torch.from_numpy(mask.astype(np.uint8)).cuda(), mode=0)
+    assert torch.equal(out0, out)
+    assert int(flags0.sum()) > 0
