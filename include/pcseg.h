@@ -125,7 +125,8 @@ int pcseg_threshold_lt_f32(const float *img, float threshold, uint8_t *mask, int
  * tiff_analysis.py:996); the float64 distance is sqrt((double)d2).  cap < 0:
  * exact everywhere; cap >= 0: values above cap are reported as cap + 1.  A
  * frame without any zero pixel follows scipy: virtual zero pixel at (-1, 0).
- * The EDT family stages 8 rows of uint16 distances in LDS: W <= 10240. */
+ * The threshold members of the EDT family (dilation, particle fill) stage 8 rows of uint16 distances plus the rows' bytes in
+ * LDS: W <= 6800. */
 size_t pcseg_edt_workspace_bytes(int B, int H, int W);
 int pcseg_edt_sq_u8(const uint8_t *mask, int32_t *d2, int B, int H, int W, int cap,
                     void *workspace, size_t workspace_bytes, pcseg_stream_t stream);

@@ -16,6 +16,7 @@ namespace pcseg {
 constexpr int EDT_CH = 32;          // rows per bit word
 constexpr int EDT_RB = 8;           // rows per horizontal-pass block
 constexpr unsigned G_INF = 0xFFFFu;  // "no zero pixel in this column"
+constexpr int EDT_STAGE_TRIPS = 4;   // column words a thread fetches as one batch when it stages a row block
 
 // ---- foreground predicates (distance is measured TO the nearest non-foreground pixel)
 struct FgNzU8 {
@@ -165,32 +166,38 @@ struct EpiD2 {
     }
 };
 // threshold epilogues only need "is there a zero pixel within sqrt(R2)": they run on edt_reach_kernel
+// The threshold epilogues work on a row block staged in LDS: `input(i)` (if kInput) is fetched for the whole block as
+// one batch of 4-byte loads, `decide` turns a staged byte and the verdict "a zero pixel is within reach" into the output
+// byte in LDS, and the block writes its rows back with 4-byte stores -- no global load sits between two steps of a scan.
 struct EpiDilate {
     static constexpr bool kThreshold = true;
+    static constexpr bool kInput = false;
     uint8_t *out;
     int r2;
     __device__ __forceinline__ int R2() const { return r2; }
-    __device__ __forceinline__ void store(int64_t i, bool within, bool any_bg, int, int, unsigned long long &) const
+    __device__ __forceinline__ const uint8_t *input() const { return nullptr; }
+    __device__ __forceinline__ uint8_t decide(uint8_t, bool within, bool any_bg, int, int, unsigned long long &) const
     {
-        out[i] = (any_bg && within) ? 1 : 0;  // empty set dilates to the empty set
+        return (any_bg && within) ? 1 : 0;  // empty set dilates to the empty set
     }
 };
 struct EpiFillParticle {
     static constexpr bool kThreshold = true;
+    static constexpr bool kInput = true;
     const uint8_t *ds;
     uint8_t *out;
     int cell_label, overlap_label, r2, thr2;  // overlap if d2 <= r2 (dilation) or d2 < thr2 (distance)
     __device__ __forceinline__ int R2() const { return max(r2, thr2 - 1); }
-    __device__ __forceinline__ void store(int64_t i, bool within, bool any_bg, int r, int c, unsigned long long &cnt) const
+    __device__ __forceinline__ const uint8_t *input() const { return ds; }
+    __device__ __forceinline__ uint8_t decide(uint8_t z, bool within, bool any_bg, int r, int c, unsigned long long &cnt) const
     {
-        uint8_t z = ds[i];
         if (z == cell_label) {
             bool ov;
             if (any_bg) ov = within;
             else ov = ((long long)(r + 1) * (r + 1) + (long long)c * c) < thr2;  // only the EDT term sees the virtual pixel
             if (ov) { z = (uint8_t)overlap_label; ++cnt; }
         }
-        out[i] = z;
+        return z;
     }
 };
 
@@ -215,15 +222,28 @@ __global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict
     const unsigned valid = rows_in_word == 32 ? 0xFFFFFFFFu : ((1u << rows_in_word) - 1u);
     const int nrows = min(RB, H - r0);
     const int64_t wbase = ((int64_t)b * nch + ch) * W;
-    for (int c = threadIdx.x; c < W; c += 256) {
-        unsigned word = bits[wbase + c];
-        unsigned u = up[wbase + c], d = dn[wbase + c];
+    // the column words of all trips are fetched as one batch (up to 4 trips = W <= 1024), then turned into distances
+    for (int cbase = 0; cbase < W; cbase += 256 * EDT_STAGE_TRIPS) {
+        unsigned wordv[EDT_STAGE_TRIPS], uv[EDT_STAGE_TRIPS], dv[EDT_STAGE_TRIPS];
 #pragma unroll
-        for (int j = 0; j < RB; ++j)
-            if (j < nrows) {
-                const unsigned v = vdist(word, valid, j0 + j, u, d, rows_in_word);
-                g2[j * P + c + 1] = v == G_INF ? EDT_D2_INF : v * v;
+        for (int t = 0; t < EDT_STAGE_TRIPS; ++t) {
+            const int c = min(cbase + (int)threadIdx.x + 256 * t, W - 1);
+            wordv[t] = bits[wbase + c];
+            uv[t] = up[wbase + c];
+            dv[t] = dn[wbase + c];
+        }
+#pragma unroll
+        for (int t = 0; t < EDT_STAGE_TRIPS; ++t) {
+            const int c = cbase + (int)threadIdx.x + 256 * t;
+            if (c < W) {
+#pragma unroll
+                for (int j = 0; j < RB; ++j)
+                    if (j < nrows) {
+                        const unsigned v = vdist(wordv[t], valid, j0 + j, uv[t], dv[t], rows_in_word);
+                        g2[j * P + c + 1] = v == G_INF ? EDT_D2_INF : v * v;
+                    }
             }
+        }
     }
     if (threadIdx.x < 2 * RB) g2[(threadIdx.x >> 1) * P + ((threadIdx.x & 1) ? W + 1 : 0)] = EDT_D2_INF;
     __syncthreads();
@@ -285,7 +305,9 @@ __global__ void __launch_bounds__(256) edt_reach_kernel(const unsigned *__restri
                                                          const uint16_t *__restrict__ dn, const int *__restrict__ any_bg,
                                                          Epi epi, unsigned long long *__restrict__ count, int H, int W, int nch)
 {
-    extern __shared__ __attribute__((aligned(16))) uint16_t g[];  // [EDT_RB][W]
+    extern __shared__ __attribute__((aligned(16))) uint16_t g[];  // [EDT_RB][W] distances, then [EDT_RB][W4] in / out bytes
+    const int W4 = (W + 3) & ~3;
+    uint8_t *zb = reinterpret_cast<uint8_t *>(g + EDT_RB * W4);
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * EDT_RB;
     const int ch = r0 / EDT_CH, j0 = r0 % EDT_CH;
@@ -293,65 +315,105 @@ __global__ void __launch_bounds__(256) edt_reach_kernel(const unsigned *__restri
     const unsigned valid = rows_in_word == 32 ? 0xFFFFFFFFu : ((1u << rows_in_word) - 1u);
     const int nrows = min(EDT_RB, H - r0);
     const int64_t wbase = ((int64_t)b * nch + ch) * W;
+    const int64_t fbase = (int64_t)b * H * W;
     const int R2 = epi.R2();
     const unsigned gmax = (unsigned)sqrtf((float)R2) + 1;  // larger distances can never be within reach
+    const bool wide = (W & 3) == 0 && ((uintptr_t)epi.out & 3) == 0 && (!Epi::kInput || ((uintptr_t)epi.input() & 3) == 0);
+    // input bytes of the block (one 4-byte load per thread and row at W = 1024, all in flight together)
+    if (Epi::kInput) {
+        const uint8_t *src = epi.input() + fbase + (int64_t)r0 * W;
+        if (wide) {
+            for (int i = threadIdx.x; i < nrows * (W / 4); i += 256) {
+                const int j = i / (W / 4), q = i % (W / 4);
+                *reinterpret_cast<unsigned *>(zb + j * W4 + 4 * q) = *reinterpret_cast<const unsigned *>(src + (int64_t)j * W + 4 * q);
+            }
+        } else {
+            for (int i = threadIdx.x; i < nrows * W; i += 256) zb[(i / W) * W4 + i % W] = src[(int64_t)(i / W) * W + i % W];
+        }
+    }
     // rows whose every column is further than that from a zero pixel vertically (most of a frame when the zero set is
     // one compact object, like the particle of fill_particle_area): nothing is within reach, no scan is needed
     bool near = false;
-    for (int c = threadIdx.x; c < W; c += 256) {
-        unsigned word = bits[wbase + c];
-        unsigned u = up[wbase + c], d = dn[wbase + c];
+    for (int cbase = 0; cbase < W; cbase += 256 * EDT_STAGE_TRIPS) {  // batched like the staging of edt_row_kernel
+        unsigned wordv[EDT_STAGE_TRIPS], uv[EDT_STAGE_TRIPS], dv[EDT_STAGE_TRIPS];
 #pragma unroll
-        for (int j = 0; j < EDT_RB; ++j)
-            if (j < nrows) {
-                const unsigned v = min(vdist(word, valid, j0 + j, u, d, rows_in_word), 0x7FFFu);
-                g[j * W + c] = (uint16_t)v;  // bit 15 stays free
-                near = near || v <= gmax;
+        for (int t = 0; t < EDT_STAGE_TRIPS; ++t) {
+            const int c = min(cbase + (int)threadIdx.x + 256 * t, W - 1);
+            wordv[t] = bits[wbase + c];
+            uv[t] = up[wbase + c];
+            dv[t] = dn[wbase + c];
+        }
+#pragma unroll
+        for (int t = 0; t < EDT_STAGE_TRIPS; ++t) {
+            const int c = cbase + (int)threadIdx.x + 256 * t;
+            if (c < W) {
+#pragma unroll
+                for (int j = 0; j < EDT_RB; ++j)
+                    if (j < nrows) {
+                        const unsigned v = min(vdist(wordv[t], valid, j0 + j, uv[t], dv[t], rows_in_word), 0x7FFFu);
+                        g[j * W4 + c] = (uint16_t)v;  // bit 15 stays free
+                        near = near || v <= gmax;
+                    }
             }
+        }
     }
     const bool any_near = __syncthreads_or(near);
     const bool anybg = any_bg[b] != 0;
-    const int64_t fbase = (int64_t)b * H * W;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int nchunks = (W + WAVE - 1) / WAVE;
     unsigned long long cnt = 0;
     if (!any_near && anybg) {
         for (int idx = threadIdx.x; idx < nrows * W; idx += 256) {
             const int j = idx / W, c = idx % W;
-            epi.store(fbase + (int64_t)(r0 + j) * W + c, false, true, r0 + j, c, cnt);
+            zb[j * W4 + c] = epi.decide(zb[j * W4 + c], false, true, r0 + j, c, cnt);
         }
-    } else
-    for (int j = wave; j < nrows; j += 4) {
-        uint16_t *gr = g + j * W;
-        int carry = -1;
-        for (int k = 0; k < nchunks; ++k) {  // left to right: furthest column reached by the intervals that start at or before c
-            const int c = k * WAVE + lane;
-            const unsigned gv = c < W ? gr[c] : 0x7FFFu;
-            int x = (gv <= gmax && (int)(gv * gv) <= R2) ? c + reach_halfwidth(gv, R2) : -1;
+    } else {
+        for (int j = wave; j < nrows; j += 4) {
+            uint16_t *gr = g + j * W4;
+            int carry = -1;
+            for (int k = 0; k < nchunks; ++k) {  // left to right: furthest column reached by the intervals that start at or before c
+                const int c = k * WAVE + lane;
+                const unsigned gv = c < W ? gr[c] : 0x7FFFu;
+                int x = (gv <= gmax && (int)(gv * gv) <= R2) ? c + reach_halfwidth(gv, R2) : -1;
+                if (__any(x >= 0)) {  // (a chunk without a single interval start -- most of them -- needs no scan)
 #pragma unroll
-            for (int off = 1; off < WAVE; off <<= 1) {
-                const int t = __shfl_up(x, off);
-                if (lane >= off) x = max(x, t);
+                    for (int off = 1; off < WAVE; off <<= 1) {
+                        const int t = __shfl_up(x, off);
+                        if (lane >= off) x = max(x, t);
+                    }
+                }
+                x = max(x, carry);
+                carry = __shfl(x, WAVE - 1);
+                if (c < W && x >= c) gr[c] = (uint16_t)(gv | 0x8000u);
             }
-            x = max(x, carry);
-            carry = __shfl(x, WAVE - 1);
-            if (c < W && x >= c) gr[c] = (uint16_t)(gv | 0x8000u);
-        }
-        carry = 0x7FFFFFFF;
-        for (int k = nchunks - 1; k >= 0; --k) {  // right to left, then the verdict
-            const int c = k * WAVE + lane;
-            const unsigned raw = c < W ? gr[c] : 0x7FFFu;
-            const unsigned gv = raw & 0x7FFFu;
-            int x = (gv <= gmax && (int)(gv * gv) <= R2) ? c - reach_halfwidth(gv, R2) : 0x7FFFFFFF;
+            carry = 0x7FFFFFFF;
+            for (int k = nchunks - 1; k >= 0; --k) {  // right to left, then the verdict
+                const int c = k * WAVE + lane;
+                const unsigned raw = c < W ? gr[c] : 0x7FFFu;
+                const unsigned gv = raw & 0x7FFFu;
+                int x = (gv <= gmax && (int)(gv * gv) <= R2) ? c - reach_halfwidth(gv, R2) : 0x7FFFFFFF;
+                if (__any(x != 0x7FFFFFFF)) {
 #pragma unroll
-            for (int off = 1; off < WAVE; off <<= 1) {
-                const int t = __shfl_down(x, off);
-                if (lane + off < WAVE) x = min(x, t);
+                    for (int off = 1; off < WAVE; off <<= 1) {
+                        const int t = __shfl_down(x, off);
+                        if (lane + off < WAVE) x = min(x, t);
+                    }
+                }
+                x = min(x, carry);
+                carry = __shfl(x, 0);
+                if (c < W) zb[j * W4 + c] = epi.decide(zb[j * W4 + c], (raw & 0x8000u) != 0 || x <= c, anybg, r0 + j, c, cnt);
             }
-            x = min(x, carry);
-            carry = __shfl(x, 0);
-            if (c < W) epi.store(fbase + (int64_t)(r0 + j) * W + c, (raw & 0x8000u) != 0 || x <= c, anybg, r0 + j, c, cnt);
         }
+    }
+    __syncthreads();
+    uint8_t *dst = epi.out + fbase + (int64_t)r0 * W;
+    if (wide) {
+        for (int i = threadIdx.x; i < nrows * (W / 4); i += 256) {
+            const int j = i / (W / 4), q = i % (W / 4);
+            *reinterpret_cast<unsigned *>(dst + (int64_t)j * W + 4 * q) = *reinterpret_cast<const unsigned *>(zb + j * W4 + 4 * q);
+        }
+    } else {
+        for (int i = threadIdx.x; i < nrows * W; i += 256) dst[(int64_t)(i / W) * W + i % W] = zb[(i / W) * W4 + i % W];
     }
     if (count) {  // per-block partial (plain store): block_counts[b][blockIdx.x], summed by edt_count_kernel
         __shared__ unsigned long long wsum[4];
@@ -412,7 +474,7 @@ static int edt_run(Fg fg, Epi epi, unsigned long long *count, int B, int H, int 
         set_error("%s: workspace too small (%zu < %zu)", who, workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
     }
-    size_t lds = (size_t)EDT_RB * W * sizeof(uint16_t);
+    size_t lds = (size_t)EDT_RB * ((W + 3) & ~3) * (sizeof(uint16_t) + 1);  // distances + the block's in / out bytes
     if (Epi::kThreshold && lds > 160 * 1024) {
         set_error("%s: W = %d too wide for the LDS row stage", who, W);
         return PCSEG_ERR_ARG;

@@ -328,6 +328,16 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
         sLV[lr * WS_P + lc] = lv;
     }
     __syncthreads();
+    // each thread remembers the level its rim cell (see the half-edge test below) had on arrival: what the tile changed
+    // on its rim is then known without going back to global memory after the sweeps
+    unsigned rim_before;
+    {
+        const int e = threadIdx.x >> 5, j = threadIdx.x & 31;
+        const int qy = e < 4 ? (e >> 1) : (e & 1), qx = e < 4 ? (e & 1) : ((e >> 1) & 1);
+        const int lr = e < 4 ? (qy ? WS_T : 1) : qy * (WS_T / 2) + j + 1;
+        const int lc = e < 4 ? qx * (WS_T / 2) + j + 1 : (qx ? WS_T : 1);
+        rim_before = sLV[lr * WS_P + lc].x;
+    }
     const SweepLine ln = ws_line();
     const int wave = threadIdx.x >> 6;
     bool changed_any = false;
@@ -355,8 +365,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
         const int r = r0 + lr - 1, c = c0 + lc - 1;
         // a tile that stopped early is not consistent inside: all four corner tiles have to look at it again
         bool ch = capped;
-        if (!capped && r >= 0 && r < H && c >= 0 && c < W)
-            ch = sLV[lr * WS_P + lc].x != (FIRST ? initial(r, c).x : L[fbase + (int64_t)r * W + c]);
+        if (!capped && r >= 0 && r < H && c >= 0 && c < W) ch = sLV[lr * WS_P + lc].x != rim_before;
         const unsigned long long half = (threadIdx.x & 32) ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
         if ((__ballot(ch) & half) && j == 0) {
             // the tile of the other tiling that holds this corner quadrant (rows r0 + qy * 32 .., cols c0 + qx * 32 ..)
@@ -880,14 +889,32 @@ __device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *_
     }
     const int r0 = ty * WS_T, c0 = tx * WS_T;
     const int64_t fbase = (int64_t)b * H * W;
-    ws_load_tile(sL, L + fbase, r0, c0, H, W, WS_INF);
-    ws_load_tile(sK, (const unsigned *)K2 + fbase, r0, c0, H, W, WS_INF);
-    for (int i = threadIdx.x; i < WS_S * WS_S; i += 256) {
-        int lr = i / WS_S, lc = i % WS_S;
-        int r = r0 + lr - 1, c = c0 + lc - 1;
-        bool in = r >= 0 && r < H && c >= 0 && c < W;
-        unsigned l = in ? L[fbase + (int64_t)r * W + c] : WS_INF;
-        sLake[lr * WS_P + lc] = in && l != WS_INF && val[fbase + (int64_t)r * W + c] < l;
+    {
+        // the three arrays of the tile + halo as ONE batch of loads per thread (clamped addresses, no branch around a
+        // load; see ws_relax_tile): a loop of dependent round trips here cost more than the sweeps
+        constexpr int TRIPS = (WS_S * WS_S + 255) / 256;
+        unsigned lv[TRIPS], kv[TRIPS], vv[TRIPS];
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = min((int)threadIdx.x + 256 * t, WS_S * WS_S - 1);
+            const int r = r0 + i / WS_S - 1, c = c0 + i % WS_S - 1;
+            const int64_t p = fbase + (int64_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1);
+            lv[t] = L[p];
+            kv[t] = K2[p];
+            vv[t] = val[p];
+        }
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = (int)threadIdx.x + 256 * t;
+            if (i < WS_S * WS_S) {
+                const int lr = i / WS_S, lc = i % WS_S;
+                const int r = r0 + lr - 1, c = c0 + lc - 1;
+                const bool in = r >= 0 && r < H && c >= 0 && c < W;
+                sL[lr * WS_P + lc] = in ? lv[t] : WS_INF;
+                sK[lr * WS_P + lc] = in ? kv[t] : WS_INF;
+                sLake[lr * WS_P + lc] = in && lv[t] != WS_INF && vv[t] < lv[t];
+            }
+        }
     }
     __syncthreads();
     const SweepLine ln = ws_line();
@@ -1258,7 +1285,10 @@ using namespace pcseg;
 // Round 0 stops every tile after this many sweeps per direction: the round after it visits every tile anyway (with the
 // other tiling), so squeezing the last changes out of isolated tiles is wasted work; a tile cut short marks all four
 // corner tiles.  Measured on the benchmark batch: 16 -> 4.6 % less relaxation time than no limit, 8 -> 1 %, 6 -> none.
-constexpr int WS_ROUND0_SWEEPS = 16;
+#ifndef PCSEG_WS_ROUND0_SWEEPS
+#define PCSEG_WS_ROUND0_SWEEPS 16
+#endif
+constexpr int WS_ROUND0_SWEEPS = PCSEG_WS_ROUND0_SWEEPS;
 
 // the watershed may be called from several host threads at once (FramePipeline's lanes)
 static std::atomic<long long> g_ws_counters[4];  // [0] unused (lives on the device), relax launches, calls, -
