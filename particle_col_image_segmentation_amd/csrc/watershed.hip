@@ -135,7 +135,7 @@ __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__res
 #define PCSEG_WS_PLAIN_STORE 0
 #endif
 #ifndef PCSEG_WS_ASM_READ
-#define PCSEG_WS_ASM_READ 0
+#define PCSEG_WS_ASM_READ 1
 #endif
 template <int STEP>
 __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
