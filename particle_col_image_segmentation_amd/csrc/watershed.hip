@@ -153,7 +153,7 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
         // for 2 x 512 B against 2 cycles per 512 B), and this kernel is bound by LDS-array cycles.  Offsets are
         // unsigned: a batch is addressed from its lowest cell.
         {
-            static_assert(WS_BATCH == 8, "the hand-written batch read is eight wide");
+            static_assert(WS_BATCH == 8 || WS_BATCH == 16, "the hand-written batch read is eight or sixteen wide");
             typedef unsigned u2v __attribute__((ext_vector_type(2)));
             constexpr int A = STEP < 0 ? -STEP : STEP;
             const int low = STEP < 0 ? base + (WS_BATCH - 1) * STEP : base;
@@ -162,9 +162,16 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
 #define PCSEG_DS_READ(j) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t[j]) : "v"(addr), "n"(8 * A * (STEP < 0 ? WS_BATCH - 1 - (j) : (j))))
             PCSEG_DS_READ(0); PCSEG_DS_READ(1); PCSEG_DS_READ(2); PCSEG_DS_READ(3);
             PCSEG_DS_READ(4); PCSEG_DS_READ(5); PCSEG_DS_READ(6); PCSEG_DS_READ(7);
-#undef PCSEG_DS_READ
+#if WS_BATCH == 16
+            PCSEG_DS_READ(8); PCSEG_DS_READ(9); PCSEG_DS_READ(10); PCSEG_DS_READ(11);
+            PCSEG_DS_READ(12); PCSEG_DS_READ(13); PCSEG_DS_READ(14); PCSEG_DS_READ(15);
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]));
+#else
             asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+#endif
+#undef PCSEG_DS_READ
 #pragma unroll
             for (int j = 0; j < WS_BATCH; ++j) lv[j] = make_uint2(t[j].x, t[j].y);
         }

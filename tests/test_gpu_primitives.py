@@ -469,3 +469,26 @@ def test_watershed_proof_holds_on_adversarial_ties(ops):
             else:
                 flagged += 1
     assert proven > 20 and flagged > 20, (proven, flagged)
+
+
+def test_threshold_rows_skip_chunks_out_of_reach(ops):
+    """Wide rows (18 chunks of 64 columns, a ragged last one): the threshold pass of the EDT skips chunks that no
+    interval starts in or reaches -- a compact particle, isolated points at chunk borders and an empty frame."""
+    H, W = 70, 1100
+    cm = np.full((4, H, W), 1, np.uint8)
+    yy, xx = np.mgrid[:H, :W]
+    cm[0][(yy - 30) ** 2 + (xx - 500) ** 2 <= 15 ** 2] = 3      # one compact particle
+    for x in (0, 63, 64, 127, 128, 640, 1087, 1099):             # single particle pixels at chunk borders
+        cm[1][(7 * x) % H, x] = 3
+    cm[2][:, 1090:] = 3                                          # a particle in the ragged last chunk only
+    cm[3][5, 700] = 2                                            # no particle pixel at all
+    cm[:, ::9, ::5] = 4                                          # pixels that are neither cell nor particle
+    out, area = ops.fill_particle(dev(cm), 3, 1, 3, 20, 2)
+    for i in range(4):
+        exp, ov = orc.fill_particle_area(cm[i], 3, 1, 3)
+        np.testing.assert_array_equal(host(out)[i], exp)
+        assert int(area[i]) == ov
+    for rad in (3, 40, 70):
+        got = host(ops.dilate_disk(dev(cm), 1 << 3, rad))
+        for i in range(4):
+            np.testing.assert_array_equal(got[i].astype(bool), orc.binary_dilation_disk(cm[i] == 3, rad))
