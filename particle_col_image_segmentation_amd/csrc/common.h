@@ -83,6 +83,31 @@ struct Carver {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
+// Inclusive prefix maximum / minimum over the 64 lanes of a wave with DPP moves only (no LDS round trip per step, which
+// is what __shfl_up costs: ds_bpermute + a wait): four shifts inside the 16-lane rows, then lane 15 of rows 0 and 2 is
+// broadcast into rows 1 and 3, then lane 31 into rows 2 and 3.  Lanes without a source keep `ident` (bound_ctrl off).
+template <bool MAX>
+__device__ __forceinline__ int wave_prefix_extreme(int x)
+{
+    constexpr int ident = MAX ? (int)0x80000000 : 0x7FFFFFFF;
+#define PCSEG_DPP_STEP(ctrl, row_mask)                                                              \
+    {                                                                                               \
+        const int t = __builtin_amdgcn_update_dpp(ident, x, ctrl, row_mask, 0xF, false);            \
+        x = MAX ? max(x, t) : min(x, t);                                                            \
+    }
+    PCSEG_DPP_STEP(0x111, 0xF)  // row_shr:1
+    PCSEG_DPP_STEP(0x112, 0xF)  // row_shr:2
+    PCSEG_DPP_STEP(0x114, 0xF)  // row_shr:4
+    PCSEG_DPP_STEP(0x118, 0xF)  // row_shr:8
+    PCSEG_DPP_STEP(0x142, 0xA)  // row_bcast:15 into rows 1 and 3
+    PCSEG_DPP_STEP(0x143, 0xC)  // row_bcast:31 into rows 2 and 3
+#undef PCSEG_DPP_STEP
+    return x;
+}
+__device__ __forceinline__ int wave_prefix_max(int x) { return wave_prefix_extreme<true>(x); }
+__device__ __forceinline__ int wave_prefix_min(int x) { return wave_prefix_extreme<false>(x); }
+__device__ __forceinline__ int wave_last_lane(int x) { return __builtin_amdgcn_readlane(x, WAVE - 1); }
+
 // XCD-aware tile order for kernels whose blocks read a halo of their neighbours' pixels.  Workgroups are dealt
 // round-robin over the 8 XCDs (blocks b and b + 8 share one; MI355X_MICROARCH.md, "Workgroup dispatch"), each XCD with
 // an L2 of its own: with the plain blockIdx -> tile map the left / right neighbour of a tile runs on ANOTHER XCD, so

@@ -375,32 +375,20 @@ __global__ void __launch_bounds__(256) edt_reach_kernel(const unsigned *__restri
                 const int c = k * WAVE + lane;
                 const unsigned gv = c < W ? gr[c] : 0x7FFFu;
                 int x = (gv <= gmax && (int)(gv * gv) <= R2) ? c + reach_halfwidth(gv, R2) : -1;
-                if (__any(x >= 0)) {  // (a chunk without a single interval start -- most of them -- needs no scan)
-#pragma unroll
-                    for (int off = 1; off < WAVE; off <<= 1) {
-                        const int t = __shfl_up(x, off);
-                        if (lane >= off) x = max(x, t);
-                    }
-                }
-                x = max(x, carry);
-                carry = __shfl(x, WAVE - 1);
+                x = max(wave_prefix_max(x), carry);
+                carry = wave_last_lane(x);
                 if (c < W && x >= c) gr[c] = (uint16_t)(gv | 0x8000u);
             }
             carry = 0x7FFFFFFF;
             for (int k = nchunks - 1; k >= 0; --k) {  // right to left, then the verdict
-                const int c = k * WAVE + lane;
+                // lanes take the chunk's columns in REVERSE order: the suffix minimum over columns is a prefix minimum
+                // over lanes (the DPP scan only runs towards higher lanes)
+                const int c = k * WAVE + (WAVE - 1 - lane);
                 const unsigned raw = c < W ? gr[c] : 0x7FFFu;
                 const unsigned gv = raw & 0x7FFFu;
                 int x = (gv <= gmax && (int)(gv * gv) <= R2) ? c - reach_halfwidth(gv, R2) : 0x7FFFFFFF;
-                if (__any(x != 0x7FFFFFFF)) {
-#pragma unroll
-                    for (int off = 1; off < WAVE; off <<= 1) {
-                        const int t = __shfl_down(x, off);
-                        if (lane + off < WAVE) x = min(x, t);
-                    }
-                }
-                x = min(x, carry);
-                carry = __shfl(x, 0);
+                x = min(wave_prefix_min(x), carry);
+                carry = wave_last_lane(x);
                 if (c < W) zb[j * W4 + c] = epi.decide(zb[j * W4 + c], (raw & 0x8000u) != 0 || x <= c, anybg, r0 + j, c, cnt);
             }
         }
