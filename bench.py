@@ -117,7 +117,8 @@ def end_to_end_leg(args, stack, cell_types, pipe, dev, world, kernel_only_mpx):
     n_batches = 6
     n_frames = n_batches * B * world
     make_batch = lambda ids: stack[:len(ids)]
-    run_sharded(B * world, make_batch, pipe, batch=B, device=dev, check=False)  # warm (sort kernels, table buffers)
+    # warm: sort kernels, and the table buffers of EVERY lane's streams (the caching allocator keeps a pool per stream)
+    run_sharded(B * world * max(1, getattr(pipe, "lanes", 1)), make_batch, pipe, batch=B, device=dev, check=False)
     pipe.synchronize()
     t0 = time.perf_counter()
     tabs = run_sharded(n_frames, make_batch, pipe, batch=B, device=dev, check=False)
@@ -130,7 +131,12 @@ def end_to_end_leg(args, stack, cell_types, pipe, dev, world, kernel_only_mpx):
     if world == 1:
         host = [stack.cpu().pin_memory() for _ in range(2)]
         up = FrameUploader((C, H, W), batch=B, device=dev)
+        for k in range(2):  # warm: the uploader's device buffers, both staging slots
+            d, ev = up.upload_staged(host[k])
+            ev.synchronize()
+            pipe.run(d).synchronize()
         pipe.synchronize()
+        up.bytes_uploaded = 0
         t0 = time.perf_counter()
         events, res = [None, None], None
         for k in range(n_batches):

@@ -122,17 +122,36 @@ __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__res
 }
 
 // (1) minimax relaxation, tile-local fixed point in LDS.  L and the pixel value share one 64-bit LDS word (x = L,
-// y = value): a sweep step is ONE ds_read_b64 instead of two ds_read_b32 -- the kernel is bound by LDS issue, and the
-// b64 form moves twice the bytes per issue slot (odd pitch: conflict-free for row and column sweeps alike).
-// one directional sweep of a line: L(i) = min(L(i), max(value(i), L(previous cell))).  Eight cells are fetched before
-// any of them is updated: the reads of a batch carry no dependency on the batch's writes (a cell is written only when
-// it is processed), and what another wave writes meanwhile is picked up an iteration later, which the monotone update
-// tolerates.  The batch loop is NOT unrolled: four direction-specific bodies have to stay resident in the I-cache.
+// y = value): a sweep step is ONE ds_read_b64 instead of two ds_read_b32 -- the kernel is bound by LDS-array cycles, and
+// the b64 form moves twice the bytes per cycle (odd pitch: conflict-free for row and column sweeps alike).
+//
+// Geometry of a relaxation tile of edge T (64 or 128; PCSEG_WS_RELAX_TILE picks, 64 is the default).  T = 128 fills the
+// 160 KB LDS of a CDNA4 CU -- the tile with its halo is 130 x 131 x 8 B = 133 KB, ONE workgroup of 16 waves per CU (as
+// many waves as four 64-tiles bring), the four 64 x 64 quadrants exchange their rims through LDS inside one iteration
+// -- and MEASURED SLOWER on the benchmark batch (3.30 ms of relaxation per step against 2.16 ms, rounds 1133 / 1121 /
+// 533 / 240 us against 742 / 606 / 327 / 175 us): with one workgroup per CU nothing runs under a tile's load, store and
+// 16-wave barriers, the shifted tiling has 81 tiles per 1024^2 frame instead of 64 (+27 %) where 64-tiles have 289
+// instead of 256 (+13 %), and the number of rounds hardly drops because levels travel along winding paths, not tile
+// diameters.
+template <int T>
+struct RelaxGeom {
+    static_assert(T == 64 || T == 128, "relaxation tiles are 64 or 128 pixels wide");
+    static constexpr int S = T + 2;        // with halo
+    static constexpr int P = T + 3;        // LDS row pitch in elements (odd)
+    static constexpr int N = S * P;        // LDS elements
+    static constexpr int G = T / 64;       // 64-line groups per direction, and 64-cell segments per line
+    static constexpr int THREADS = 4 * G * G * 64;  // one wave per (direction, line group, segment)
+    static constexpr int HE = T / 2;       // cells of a half edge
+    static constexpr size_t LDS_BYTES = sizeof(uint2) * N;
+};
+
+// one directional sweep of a 64-cell segment of a line: L(i) = min(L(i), max(value(i), L(previous cell))).  Eight cells
+// are fetched before any of them is updated: the reads of a batch carry no dependency on the batch's writes (a cell is
+// written only when it is processed), and what another wave writes meanwhile is picked up an iteration later, which
+// the monotone update tolerates.  The batch loop is NOT unrolled: four direction-specific bodies have to stay resident
+// in the I-cache.
 #ifndef WS_BATCH
 #define WS_BATCH 8
-#endif
-#ifndef PCSEG_WS_PLAIN_STORE
-#define PCSEG_WS_PLAIN_STORE 0
 #endif
 #ifndef PCSEG_WS_ASM_READ
 #define PCSEG_WS_ASM_READ 1
@@ -145,7 +164,7 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
     unsigned prev = sLV[start].x;
     int base = start + STEP;
 #pragma unroll 1
-    for (int k0 = 0; k0 < WS_T; k0 += WS_BATCH, base += WS_BATCH * STEP) {
+    for (int k0 = 0; k0 < 64; k0 += WS_BATCH, base += WS_BATCH * STEP) {
         uint2 lv[WS_BATCH];
 #if PCSEG_WS_ASM_READ
         // The eight reads are written as ds_read_b64 by hand: the compiler pairs neighbouring reads into ds_read2_b64,
@@ -194,26 +213,11 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
             prev = nw[j];
         }
         if (__any(batch_diff != 0)) {
-#if PCSEG_WS_PLAIN_STORE
-            // Plain stores instead of LDS atomics, and only of cells this lane LOWERED below what it read (the others
-            // go to the lane's pad word, column 66 of its row: a select on the address, nothing under an exec mask).
-            // A store may overwrite a lower value another wave wrote since the batch was read; that is harmless:
-            // every value ever stored is a level of a real path (>= the fixed point), every store writes less than some
-            // value the cell held earlier in the same iteration, so the image at the barrier decreases strictly in
-            // every cell that was stored to -- the iteration count is finite -- and an iteration without a single store
-            // read a stable image that satisfies all four directional inequalities, i.e. the fixed point.
-            unsigned *pad = sLw + 2 * (((int)(threadIdx.x & 63) + 1) * WS_P + WS_S);
-#pragma unroll
-            for (int j = 0; j < WS_BATCH; ++j) {
-                unsigned *dst = nw[j] < lv[j].x ? &sLw[2 * (base + j * STEP)] : pad;
-                *dst = nw[j];
-            }
-#else
-            // unconditional LDS atomic min per cell: nothing under an exec mask (a compare + masked store per step cost
-            // 10 % more), and still monotone when another wave lowered the cell since the batch was read
+            // unconditional LDS atomic min per cell: nothing under an exec mask (compare + store to the cell or to a pad
+            // word measured 13 % slower, a compare + masked store 10 %), and still monotone when another wave lowered
+            // the cell since the batch was read
 #pragma unroll
             for (int j = 0; j < WS_BATCH; ++j) atomicMin(&sLw[2 * (base + j * STEP)], nw[j]);
-#endif
             diff |= batch_diff;
         }
     }
@@ -233,8 +237,8 @@ struct WsInputs {
 };
 
 //
-// Rounds ALTERNATE between two tilings: tile (tx, ty) starts at (ty * 64 - off, tx * 64 - off) with off = 0 in even
-// rounds and 32 in odd ones, so the tile borders of one round are tile centres of the next and a path that winds
+// Rounds ALTERNATE between two tilings: tile (tx, ty) starts at (ty * T - off, tx * T - off) with off = 0 in even
+// rounds and T / 2 in odd ones, so the tile borders of one round are tile centres of the next and a path that winds
 // across a border is resolved inside one tile a round later instead of costing a round per crossing.  Which tiles the
 // next round has to visit follows from the half edges that changed: after a tile reached its fixed point its cells are
 // consistent with each other, a violated pixel can only sit on the tile's rim next to a neighbour outside, and rim
@@ -242,28 +246,32 @@ struct WsInputs {
 // corner.  So each tile marks, per corner quadrant, that corner's tile if one of the quadrant's two outer half
 // edges changed.  (grid = this round's tiling, dirty_in in its layout; dirty_out in the other tiling's layout.)
 struct WsTiling {
-    int off;     // 0 or WS_T / 2
+    int off;     // 0 or T / 2
     int nx, ny;  // tiles per frame in x and y
 };
 
-// One tile of one round (block-uniform control flow: every return is taken by all 256 threads).
+// One tile of one round (block-uniform control flow: every return is taken by all threads of the block).
+template <int T>
 __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, const bool FIRST, unsigned *__restrict__ val,
                                               unsigned *__restrict__ L, uint8_t *__restrict__ dirty_in,
                                               uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed, int H, int W,
                                               const WsTiling &cur, const WsTiling &nxt, int max_iter, int tx, int ty, int b)
 {
+    using G = RelaxGeom<T>;
+    constexpr int S = G::S, P = G::P, NT = G::THREADS, QW = T / 4;  // QW: 16-byte quads per tile row
+    const int tid = threadIdx.x;
     if (!FIRST) {
         // a visited tile takes its mark down itself: the buffer is all zero again when it becomes the output of the
         // round after next, and no memset has to sit between two rounds
         uint8_t *mark = dirty_in + ((int64_t)b * cur.ny + ty) * cur.nx + tx;
         if (!*mark) return;
         __syncthreads();
-        if (threadIdx.x == 0) *mark = 0;
+        if (tid == 0) *mark = 0;
     }
-    // tiles actually processed (measurement: bench.py roofline), spread over 16 cache lines: one counter would make
-    // every block of the launch queue on the same line
-    if (threadIdx.x == 0) atomicAdd(any_changed + WS_CNT0 + WS_CNT_STRIDE * ((tx + 5 * ty + 3 * b) & 15), 1);
-    const int r0 = ty * WS_T - cur.off, c0 = tx * WS_T - cur.off;
+    // 64 x 64 units actually processed (measurement: bench.py roofline), spread over 16 cache lines: one counter would
+    // make every block of the launch queue on the same line
+    if (tid == 0) atomicAdd(any_changed + WS_CNT0 + WS_CNT_STRIDE * ((tx + 5 * ty + 3 * b) & 15), G::G * G::G);
+    const int r0 = ty * T - cur.off, c0 = tx * T - cur.off;
     const int64_t fbase = (int64_t)b * H * W;
     // (L, value) of a pixel before any relaxation
     auto initial = [&](int r, int c) -> uint2 {
@@ -276,13 +284,13 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
         // The tile load is ONE batch of loads per thread, not a loop of dependent round trips: every access goes to a
         // clamped (always valid) address without a branch, so that the unrolled loop is a single basic block whose
         // loads the compiler issues back to back, and the out-of-frame cells are fixed up by a select afterwards.
-        // Interior columns as 16-byte quads (66 rows x 16 quads over 256 threads: 5 trips), the two halo columns as one
-        // scalar trip.  (A loop with an `if (inside)` around each load measured one full memory latency per trip:
-        // 17 trips, i.e. most of a revisited tile's time.)
-        constexpr int QUADS = WS_S * (WS_T / 4), TRIPS = (QUADS + 255) / 256;
+        // Interior columns as 16-byte quads (S rows x T / 4 quads: 5 trips), the two halo columns as one scalar trip.
+        // (A loop with an `if (inside)` around each load measured one full memory latency per trip: 17 trips, i.e.
+        // most of a revisited tile's time.)
+        constexpr int QUADS = S * QW, TRIPS = (QUADS + NT - 1) / NT;
         const float *img_f = in.img + (int64_t)b * in.frame_stride;
-        const bool halo_thread = threadIdx.x < 2 * WS_S;
-        const int h_lr = threadIdx.x >> 1, h_lc = (threadIdx.x & 1) ? WS_S - 1 : 0;
+        const bool halo_thread = tid < 2 * S;
+        const int h_lr = tid >> 1, h_lc = (tid & 1) ? S - 1 : 0;
         const int h_r = r0 + h_lr - 1, h_c = c0 + h_lc - 1;
         const bool h_in = halo_thread && h_r >= 0 && h_r < H && h_c >= 0 && h_c < W;
         const int64_t h_p = (int64_t)min(max(h_r, 0), H - 1) * W + min(max(h_c, 0), W - 1);
@@ -292,8 +300,8 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             unsigned k4[TRIPS];
 #pragma unroll
             for (int t = 0; t < TRIPS; ++t) {
-                const int idx = min((int)threadIdx.x + 256 * t, QUADS - 1);
-                const int lr = idx >> 4, q = idx & 15;
+                const int idx = min(tid + NT * t, QUADS - 1);
+                const int lr = idx / QW, q = idx % QW;
                 const int64_t p = (int64_t)min(max(r0 + lr - 1, 0), H - 1) * W + min(max(c0 + 4 * q, 0), W - 4);
                 f4[t] = *reinterpret_cast<const float4 *>(img_f + p);
                 m4[t] = *reinterpret_cast<const int4 *>(in.markers + fbase + p);
@@ -304,9 +312,9 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             const uint8_t hk = in.mask[fbase + h_p];
 #pragma unroll
             for (int t = 0; t < TRIPS; ++t) {
-                const int idx = (int)threadIdx.x + 256 * t;
+                const int idx = tid + NT * t;
                 if (idx < QUADS) {
-                    const int lr = idx >> 4, q = idx & 15;
+                    const int lr = idx / QW, q = idx % QW;
                     const int r = r0 + lr - 1, c = c0 + 4 * q;
                     const bool inside = r >= 0 && r < H && c >= 0 && c < W;
                     const float fv[4] = {f4[t].x, f4[t].y, f4[t].z, f4[t].w};
@@ -318,9 +326,9 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
                         const bool msk = inside && ((k4[t] >> (8 * j)) & 255u) != 0;
                         key[j] = msk ? ws_key(fv[j]) : WS_INF;
                         lab[j] = msk ? mv[j] : 0;
-                        sLV[lr * WS_P + 1 + 4 * q + j] = make_uint2(lab[j] != 0 ? key[j] : WS_INF, key[j]);
+                        sLV[lr * P + 1 + 4 * q + j] = make_uint2(lab[j] != 0 ? key[j] : WS_INF, key[j]);
                     }
-                    if (inside && lr >= 1 && lr <= WS_T) {  // own pixels: publish value keys and seed labels
+                    if (inside && lr >= 1 && lr <= T) {  // own pixels: publish value keys and seed labels
                         const int64_t g = fbase + (int64_t)r * W + c;
                         *reinterpret_cast<uint4 *>(val + g) = make_uint4(key[0], key[1], key[2], key[3]);
                         *reinterpret_cast<int4 *>(in.out + g) = make_int4(lab[0], lab[1], lab[2], lab[3]);
@@ -330,14 +338,14 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             if (halo_thread) {
                 const bool msk = h_in && hk != 0;
                 const unsigned key = msk ? ws_key(hf) : WS_INF;
-                sLV[h_lr * WS_P + h_lc] = make_uint2(msk && hm != 0 ? key : WS_INF, key);
+                sLV[h_lr * P + h_lc] = make_uint2(msk && hm != 0 ? key : WS_INF, key);
             }
         } else {
             uint4 l4[TRIPS], v4[TRIPS];
 #pragma unroll
             for (int t = 0; t < TRIPS; ++t) {
-                const int idx = min((int)threadIdx.x + 256 * t, QUADS - 1);
-                const int lr = idx >> 4, q = idx & 15;
+                const int idx = min(tid + NT * t, QUADS - 1);
+                const int lr = idx / QW, q = idx % QW;
                 const int64_t p = fbase + (int64_t)min(max(r0 + lr - 1, 0), H - 1) * W + min(max(c0 + 4 * q, 0), W - 4);
                 l4[t] = *reinterpret_cast<const uint4 *>(L + p);
                 v4[t] = *reinterpret_cast<const uint4 *>(val + p);
@@ -345,29 +353,29 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             const unsigned hl = L[fbase + h_p], hv = val[fbase + h_p];
 #pragma unroll
             for (int t = 0; t < TRIPS; ++t) {
-                const int idx = (int)threadIdx.x + 256 * t;
+                const int idx = tid + NT * t;
                 if (idx < QUADS) {
-                    const int lr = idx >> 4, q = idx & 15;
+                    const int lr = idx / QW, q = idx % QW;
                     const int r = r0 + lr - 1, c = c0 + 4 * q;
                     const bool inside = r >= 0 && r < H && c >= 0 && c < W;
-                    uint2 *dst = sLV + lr * WS_P + 1 + 4 * q;
+                    uint2 *dst = sLV + lr * P + 1 + 4 * q;
                     dst[0] = inside ? make_uint2(l4[t].x, v4[t].x) : make_uint2(WS_INF, WS_INF);
                     dst[1] = inside ? make_uint2(l4[t].y, v4[t].y) : make_uint2(WS_INF, WS_INF);
                     dst[2] = inside ? make_uint2(l4[t].z, v4[t].z) : make_uint2(WS_INF, WS_INF);
                     dst[3] = inside ? make_uint2(l4[t].w, v4[t].w) : make_uint2(WS_INF, WS_INF);
                 }
             }
-            if (halo_thread) sLV[h_lr * WS_P + h_lc] = h_in ? make_uint2(hl, hv) : make_uint2(WS_INF, WS_INF);
+            if (halo_thread) sLV[h_lr * P + h_lc] = h_in ? make_uint2(hl, hv) : make_uint2(WS_INF, WS_INF);
         }
     } else
-    for (int i = threadIdx.x; i < WS_S * WS_S; i += 256) {
-        int lr = i / WS_S, lc = i % WS_S;
+    for (int i = tid; i < S * S; i += NT) {
+        int lr = i / S, lc = i % S;
         int r = r0 + lr - 1, c = c0 + lc - 1;
         uint2 lv = make_uint2(WS_INF, WS_INF);
         if (r >= 0 && r < H && c >= 0 && c < W) {
             if (FIRST) {
                 lv = initial(r, c);
-                if (lr >= 1 && lr <= WS_T && lc >= 1 && lc <= WS_T) {  // own pixels: publish value key and seed label
+                if (lr >= 1 && lr <= T && lc >= 1 && lc <= T) {  // own pixels: publish value key and seed label
                     const int64_t g = fbase + (int64_t)r * W + c;
                     val[g] = lv.y;
                     in.out[g] = lv.y != WS_INF ? in.markers[g] : 0;
@@ -377,51 +385,51 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
                 lv.y = val[fbase + (int64_t)r * W + c];
             }
         }
-        sLV[lr * WS_P + lc] = lv;
+        sLV[lr * P + lc] = lv;
     }
     __syncthreads();
-    // each thread remembers the level its rim cell (see the half-edge test below) had on arrival: what the tile changed
-    // on its rim is then known without going back to global memory after the sweeps
-    unsigned rim_before;
-    {
-        const int e = threadIdx.x >> 5, j = threadIdx.x & 31;
-        const int qy = e < 4 ? (e >> 1) : (e & 1), qx = e < 4 ? (e & 1) : ((e >> 1) & 1);
-        const int lr = e < 4 ? (qy ? WS_T : 1) : qy * (WS_T / 2) + j + 1;
-        const int lc = e < 4 ? qx * (WS_T / 2) + j + 1 : (qx ? WS_T : 1);
-        rim_before = sLV[lr * WS_P + lc].x;
-    }
-    const SweepLine ln = ws_line();
-    const int wave = threadIdx.x >> 6;
+    // thread = (half edge e, cell j): e 0..3 horizontal (top-left, top-right, bottom-left, bottom-right), e 4..7 vertical
+    // (left-top, left-bottom, right-top, right-bottom).  Each of the first 8 * T / 2 threads remembers the level its rim
+    // cell had on arrival: what the tile changed on its rim is then known without going back to global memory
+    const bool rim_thread = tid < 8 * G::HE;
+    const int e = tid / G::HE, ej = tid % G::HE;
+    const int qy = e < 4 ? (e >> 1) : (e & 1), qx = e < 4 ? (e & 1) : ((e >> 1) & 1);
+    const int rim_lr = e < 4 ? (qy ? T : 1) : qy * G::HE + ej + 1;
+    const int rim_lc = e < 4 ? qx * G::HE + ej + 1 : (qx ? T : 1);
+    const unsigned rim_before = rim_thread ? sLV[rim_lr * P + rim_lc].x : 0u;
+    // wave = (direction, group of 64 lines, 64-cell segment of the lines): the segments of a line are swept at the same
+    // time, each starting from the cell in front of it -- its neighbour segment's last cell, or the halo
+    const int wave = tid >> 6, lane = tid & 63;
+    const int dir = wave & 3, seg = wave >> 2;
+    const int line = 1 + (seg % G::G) * 64 + lane, along = (seg / G::G) * 64;
+    const int start = dir == 0 ? line * P + along : dir == 1 ? line * P + (S - 1) - along
+                    : dir == 2 ? along * P + line : ((S - 1) - along) * P + line;
     bool changed_any = false;
     bool capped = true;  // left before the tile's fixed point (round 0 stops after max_iter sweeps per direction)
     for (int iter = 0; iter < max_iter; ++iter) {
         // one code path per direction: the step is a compile-time constant there, so the LDS addresses of a batch are
         // base + constant
         bool changed;
-        if (wave == 0) changed = ws_sweep<1>(sLV, ln.start);
-        else if (wave == 1) changed = ws_sweep<-1>(sLV, ln.start);
-        else if (wave == 2) changed = ws_sweep<WS_P>(sLV, ln.start);
-        else changed = ws_sweep<-WS_P>(sLV, ln.start);
+        if (dir == 0) changed = ws_sweep<1>(sLV, start);
+        else if (dir == 1) changed = ws_sweep<-1>(sLV, start);
+        else if (dir == 2) changed = ws_sweep<P>(sLV, start);
+        else changed = ws_sweep<-P>(sLV, start);
         if (!__syncthreads_or(changed)) { capped = false; break; }
         changed_any = true;
     }
     if (!FIRST && !changed_any) return;
-    // half edges that changed (compare with what is still in global memory) -> tiles of the next round; then store
+    // half edges that changed -> tiles of the next round; then store
     if (changed_any) {
-        // thread = (half edge e, cell j): e 0..3 horizontal (top-left, top-right, bottom-left, bottom-right), e 4..7
-        // vertical (left-top, left-bottom, right-top, right-bottom); each half edge is one half wave
-        const int e = threadIdx.x >> 5, j = threadIdx.x & 31;
-        const int qy = e < 4 ? (e >> 1) : (e & 1), qx = e < 4 ? (e & 1) : ((e >> 1) & 1);
-        const int lr = e < 4 ? (qy ? WS_T : 1) : qy * (WS_T / 2) + j + 1;
-        const int lc = e < 4 ? qx * (WS_T / 2) + j + 1 : (qx ? WS_T : 1);
-        const int r = r0 + lr - 1, c = c0 + lc - 1;
+        const int r = r0 + rim_lr - 1, c = c0 + rim_lc - 1;
         // a tile that stopped early is not consistent inside: all four corner tiles have to look at it again
-        bool ch = capped;
-        if (!capped && r >= 0 && r < H && c >= 0 && c < W) ch = sLV[lr * WS_P + lc].x != rim_before;
-        const unsigned long long half = (threadIdx.x & 32) ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
-        if ((__ballot(ch) & half) && j == 0) {
-            // the tile of the other tiling that holds this corner quadrant (rows r0 + qy * 32 .., cols c0 + qx * 32 ..)
-            const int oy = (r0 + qy * (WS_T / 2) + nxt.off) / WS_T, ox = (c0 + qx * (WS_T / 2) + nxt.off) / WS_T;
+        bool ch = rim_thread && capped;
+        if (rim_thread && !capped && r >= 0 && r < H && c >= 0 && c < W) ch = sLV[rim_lr * P + rim_lc].x != rim_before;
+        // the lanes of this thread's half edge inside its wave
+        const unsigned long long mine = G::HE >= 64 ? ~0ull : (((1ull << (G::HE & 63)) - 1ull) << ((tid & 63) / G::HE * G::HE));
+        const unsigned long long edge_changed = __ballot(ch) & mine;
+        if (rim_thread && edge_changed && ej == 0) {
+            // the tile of the other tiling that holds this corner quadrant (rows r0 + qy * T / 2 .., cols c0 + qx * T / 2 ..)
+            const int oy = (r0 + qy * G::HE + nxt.off) / T, ox = (c0 + qx * G::HE + nxt.off) / T;
             if (oy >= 0 && oy < nxt.ny && ox >= 0 && ox < nxt.nx) {
                 dirty_out[((int64_t)b * nxt.ny + oy) * nxt.nx + ox] = 1;
             }
@@ -430,30 +438,31 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
     __syncthreads();
     if (in.vec) {
 #pragma unroll
-        for (int t = 0; t < WS_T * (WS_T / 4) / 256; ++t) {
-            const int idx = threadIdx.x + 256 * t, lr = idx >> 4, q = idx & 15;
+        for (int t = 0; t < T * QW / NT; ++t) {
+            const int idx = tid + NT * t, lr = idx / QW, q = idx % QW;
             const int r = r0 + lr, c = c0 + 4 * q;
-            const uint2 *src = sLV + (lr + 1) * WS_P + 1 + 4 * q;
+            const uint2 *src = sLV + (lr + 1) * P + 1 + 4 * q;
             if (r >= 0 && r < H && c >= 0 && c < W)
                 *reinterpret_cast<uint4 *>(L + fbase + (int64_t)r * W + c) = make_uint4(src[0].x, src[1].x, src[2].x, src[3].x);
         }
         return;
     }
-    for (int i = threadIdx.x; i < WS_T * WS_T; i += 256) {
-        int lr = i / WS_T, lc = i % WS_T;
+    for (int i = tid; i < T * T; i += NT) {
+        int lr = i / T, lc = i % T;
         int r = r0 + lr, c = c0 + lc;
-        if (r >= 0 && r < H && c >= 0 && c < W) L[fbase + (int64_t)r * W + c] = sLV[(lr + 1) * WS_P + lc + 1].x;
+        if (r >= 0 && r < H && c >= 0 && c < W) L[fbase + (int64_t)r * W + c] = sLV[(lr + 1) * P + lc + 1].x;
     }
 }
 
-__global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool FIRST, unsigned *__restrict__ val,
-                                                        unsigned *__restrict__ L, uint8_t *__restrict__ dirty_in,
-                                                        uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed, int H, int W,
-                                                        WsTiling cur, WsTiling nxt, int max_iter)
+template <int T>
+__global__ void __launch_bounds__(RelaxGeom<T>::THREADS) ws_relax_kernel(WsInputs in, const bool FIRST, unsigned *__restrict__ val,
+                                                                         unsigned *__restrict__ L, uint8_t *__restrict__ dirty_in,
+                                                                         uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed,
+                                                                         int H, int W, WsTiling cur, WsTiling nxt, int max_iter)
 {
-    __shared__ uint2 sLV[WS_N];
+    extern __shared__ __attribute__((aligned(16))) uint2 relax_lds[];  // RelaxGeom<T>::N cells
     const TileIndex t = xcd_tile_index();  // a tile's halo is its neighbours' rim: keep them on one XCD's L2
-    ws_relax_tile(sLV, in, FIRST, val, L, dirty_in, dirty_out, any_changed, H, W, cur, nxt, max_iter, t.x, t.y, t.z);
+    ws_relax_tile<T>(relax_lds, in, FIRST, val, L, dirty_in, dirty_out, any_changed, H, W, cur, nxt, max_iter, t.x, t.y, t.z);
 }
 
 // The fixed point is driven WITHOUT the host: a fixed number of grid rounds is enqueued (a round whose tiles carry no
@@ -461,12 +470,14 @@ __global__ void __launch_bounds__(256) ws_relax_kernel(WsInputs in, const bool F
 // a few tiles of a few frames, if anything -- is finished by this kernel: one block per frame walks the frame's marked
 // tiles round by round until a round marks nothing.  Rounds of one frame only depend on that frame's tiles, so the
 // block's own barrier is the only synchronisation (stores and loads of one workgroup go through the same L1).
-__global__ void __launch_bounds__(256) ws_relax_tail_kernel(WsInputs in, unsigned *__restrict__ val, unsigned *__restrict__ L,
-                                                             uint8_t *__restrict__ dirtyA, uint8_t *__restrict__ dirtyB,
-                                                             int *__restrict__ any_changed, int *__restrict__ not_converged, int H,
-                                                             int W, WsTiling t0, WsTiling t1, int first_round, int max_rounds)
+template <int T>
+__global__ void __launch_bounds__(RelaxGeom<T>::THREADS) ws_relax_tail_kernel(WsInputs in, unsigned *__restrict__ val,
+                                                                              unsigned *__restrict__ L, uint8_t *__restrict__ dirtyA,
+                                                                              uint8_t *__restrict__ dirtyB, int *__restrict__ any_changed,
+                                                                              int *__restrict__ not_converged, int H, int W,
+                                                                              WsTiling t0, WsTiling t1, int first_round, int max_rounds)
 {
-    __shared__ uint2 sLV[WS_N];
+    extern __shared__ __attribute__((aligned(16))) uint2 relax_lds[];
     const int b = blockIdx.x;
     uint8_t *din = dirtyA, *dout = dirtyB;
     for (int round = first_round;; ++round) {
@@ -474,14 +485,14 @@ __global__ void __launch_bounds__(256) ws_relax_tail_kernel(WsInputs in, unsigne
         const int ntiles = cur.nx * cur.ny;
         const uint8_t *marks = din + (int64_t)b * ntiles;
         bool any = false;
-        for (int t = threadIdx.x; t < ntiles; t += 256) any = any || marks[t] != 0;
+        for (int t = threadIdx.x; t < ntiles; t += RelaxGeom<T>::THREADS) any = any || marks[t] != 0;
         if (!__syncthreads_or(any)) return;
         if (round - first_round >= max_rounds) {  // cannot happen for a monotone fixed point; never spin for ever
             if (threadIdx.x == 0) *not_converged = 1;
             return;
         }
         for (int t = 0; t < ntiles; ++t) {
-            ws_relax_tile(sLV, in, false, val, L, din, dout, any_changed, H, W, cur, nxt, 100000, t % cur.nx, t / cur.nx, b);
+            ws_relax_tile<T>(relax_lds, in, false, val, L, din, dout, any_changed, H, W, cur, nxt, 100000, t % cur.nx, t / cur.nx, b);
             __syncthreads();  // the tile's stores (L, marks) before the next tile loads its halo / the next round scans
         }
         uint8_t *tmp = din; din = dout; dout = tmp;
@@ -1337,6 +1348,9 @@ using namespace pcseg;
 // Round 0 stops every tile after this many sweeps per direction: the round after it visits every tile anyway (with the
 // other tiling), so squeezing the last changes out of isolated tiles is wasted work; a tile cut short marks all four
 // corner tiles.  Measured on the benchmark batch: 16 -> 4.6 % less relaxation time than no limit, 8 -> 1 %, 6 -> none.
+#ifndef PCSEG_WS_RELAX_TILE
+#define PCSEG_WS_RELAX_TILE 64
+#endif
 #ifndef PCSEG_WS_ROUND0_SWEEPS
 #define PCSEG_WS_ROUND0_SWEEPS 16
 #endif
@@ -1447,7 +1461,21 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                          ((uintptr_t)mask & 3) == 0;
         const WsInputs inputs{img, frame_stride, markers, mask, out, vec};
         // minimax relaxation over alternating tilings
-        const WsTiling tilings[2] = {{0, tilesX, tilesY}, {WS_T / 2, (W + WS_T / 2 + WS_T - 1) / WS_T, (H + WS_T / 2 + WS_T - 1) / WS_T}};
+        constexpr int RT = PCSEG_WS_RELAX_TILE;  // edge of a relaxation tile (the later stages keep their 64 x 64 tiles)
+        using RG = RelaxGeom<RT>;
+        const WsTiling tilings[2] = {{0, (W + RT - 1) / RT, (H + RT - 1) / RT},
+                                     {RT / 2, (W + RT / 2 + RT - 1) / RT, (H + RT / 2 + RT - 1) / RT}};
+        static std::atomic<bool> lds_attr_set[64];
+        {
+            int dev = 0;
+            if (RG::LDS_BYTES > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !lds_attr_set[dev].load()) {
+                PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)ws_relax_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)RG::LDS_BYTES));
+                PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)ws_relax_tail_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)RG::LDS_BYTES));
+                lds_attr_set[dev].store(true);
+            }
+        }
         // both mark buffers start empty (round 0 visits every tile regardless)
         PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, ntiles_max, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(dirtyB, 0, ntiles_max, s));
@@ -1455,14 +1483,14 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             uint8_t *din = dirtyA, *dout = dirtyB;
             for (int round = 0; round < WS_GRID_ROUNDS; ++round) {
                 const WsTiling &cur = tilings[round & 1], &nxt = tilings[(round + 1) & 1];
-                PCSEG_LAUNCH(ws_relax_kernel, dim3(cur.nx, cur.ny, B), dim3(256), 0, s, inputs, round == 0, val, L, din, dout, changed,
-                             H, W, cur, nxt, round == 0 ? WS_ROUND0_SWEEPS : 100000);
+                PCSEG_LAUNCH(ws_relax_kernel<RT>, dim3(cur.nx, cur.ny, B), dim3(RG::THREADS), RG::LDS_BYTES, s, inputs, round == 0, val,
+                             L, din, dout, changed, H, W, cur, nxt, round == 0 ? WS_ROUND0_SWEEPS : 100000);
                 PCSEG_CHECK_LAUNCH();
                 ++relax_launches;
                 uint8_t *t = din; din = dout; dout = t;
             }
-            PCSEG_LAUNCH(ws_relax_tail_kernel, dim3(B), dim3(256), 0, s, inputs, val, L, din, dout, changed, changed + 6, H, W,
-                         tilings[0], tilings[1], WS_GRID_ROUNDS, max_rounds);
+            PCSEG_LAUNCH(ws_relax_tail_kernel<RT>, dim3(B), dim3(RG::THREADS), RG::LDS_BYTES, s, inputs, val, L, din, dout, changed,
+                         changed + 6, H, W, tilings[0], tilings[1], WS_GRID_ROUNDS, max_rounds);
             PCSEG_CHECK_LAUNCH();
         }
         const dim3 ugrid_full((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B);

@@ -21,7 +21,7 @@ def main(root):
             for r in csv.DictReader(fh):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    relax = [(s, e) for s, e, n in rows if n.startswith("pcseg::ws_relax_kernel") or "ws_relax_kernel(" in n]
+    relax = [(s, e) for s, e, n in rows if "ws_relax_kernel" in n]
     if not relax:
         raise SystemExit("no ws_relax_kernel dispatches found")
     # split into watershed calls: a gap of more than 1 ms between two relax launches starts a new call
