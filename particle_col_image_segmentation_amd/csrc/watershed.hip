@@ -1348,6 +1348,12 @@ using namespace pcseg;
 // Round 0 stops every tile after this many sweeps per direction: the round after it visits every tile anyway (with the
 // other tiling), so squeezing the last changes out of isolated tiles is wasted work; a tile cut short marks all four
 // corner tiles.  Measured on the benchmark batch: 16 -> 4.6 % less relaxation time than no limit, 8 -> 1 %, 6 -> none.
+#ifndef PCSEG_WS_ROUND_SWEEPS
+// later grid rounds: same limit (a tile cut short marks its four corner tiles and is finished by them or by a later round;
+// the per-frame tail kernel has no limit).  Relaxation per launch on the benchmark batch: no limit 179.9 us, 32 -> 177.5,
+// 16 -> 170.5, 8 -> 175.1 plus 122 us of tail kernel.
+#define PCSEG_WS_ROUND_SWEEPS 16
+#endif
 #ifndef PCSEG_WS_RELAX_TILE
 #define PCSEG_WS_RELAX_TILE 64
 #endif
@@ -1484,7 +1490,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             for (int round = 0; round < WS_GRID_ROUNDS; ++round) {
                 const WsTiling &cur = tilings[round & 1], &nxt = tilings[(round + 1) & 1];
                 PCSEG_LAUNCH(ws_relax_kernel<RT>, dim3(cur.nx, cur.ny, B), dim3(RG::THREADS), RG::LDS_BYTES, s, inputs, round == 0, val,
-                             L, din, dout, changed, H, W, cur, nxt, round == 0 ? WS_ROUND0_SWEEPS : 100000);
+                             L, din, dout, changed, H, W, cur, nxt, round == 0 ? WS_ROUND0_SWEEPS : PCSEG_WS_ROUND_SWEEPS);
                 PCSEG_CHECK_LAUNCH();
                 ++relax_launches;
                 uint8_t *t = din; din = dout; dout = t;
