@@ -373,7 +373,7 @@ def _run(args):
                        "tie_fallback_frames_last_step": tie_frames, "reference_nan_frames_rank0": nan_frames,
                        "gathered_roi_rows": n_rois, "table_assembly_ms_last_batch": round(table_ms, 3),
                        "roi_table_all_gather_ms": round(gather_ms, 3)},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "launches_per_step": dom_calls / args.steps,
+            "roofline": {"bound": "hbm", "kernel": short, "launches_per_step": dom_calls / args.steps,
                          "avg_launch_us": round(1e6 * avg_s, 2), "algorithmic_bytes_per_pixel": bpp,
                          "algorithmic_bytes_per_launch": round(launch_bytes),
                          "pixels_per_launch": round(units),
