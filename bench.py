@@ -59,7 +59,7 @@ def parse_args():
                     help="profiling aid, not the headline: both kernel chains on one stream, so that per-kernel durations "
                          "are not inflated by the other chain's kernels sharing the CUs")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the dataset / PCIe legs")
-    ap.add_argument("--secondary-batch", type=int, default=1024,
+    ap.add_argument("--secondary-batch", type=int, default=2560,
                     help="frames of the SECONDARY leg (0 = off): one batch with the boundary plane quantised to k/100, the "
                          "realistic ilastik-random-forest input on which every frame floods through ties; reported as "
                          "\"secondary\" next to the headline, never as `value`")
@@ -167,6 +167,7 @@ def secondary_leg(args, stack, cell_types, pipe):
     big = stack.repeat(reps, 1, 1, 1)
     n, H, W = big.shape[0], big.shape[2], big.shape[3]
     pipe.synchronize()
+    torch.cuda.empty_cache()   # the headline legs' cached blocks: this batch wants most of the card
     solo = type(pipe)(cell_types, lanes=1)
     res = solo.run(big)        # allocator priming on the tie-free frames (same sizes, milliseconds)
     res.synchronize()

@@ -1123,7 +1123,14 @@ __global__ void ws_set_flags_kernel(int *flags, int B, int v)
 // larger calls, where throughput comes from the number of frames in flight -- the flood of a frame is sequential by
 // definition, so a batch of N frames uses N waves whatever else is done, and 16+ of them fit a CU once the LDS share
 // is small.  Both sizes keep every six-level window entirely in LDS or entirely in the workspace.
-constexpr int EX_LDS_BIG = 8192, EX_LDS_SMALL = 128;
+#ifndef PCSEG_EX_SMALL_LDS
+#define PCSEG_EX_SMALL_LDS 128
+#endif
+#ifndef PCSEG_EX_SMALL_D
+#define PCSEG_EX_SMALL_D 6
+#endif
+constexpr int EX_LDS_BIG = 8192, EX_LDS_SMALL = PCSEG_EX_SMALL_LDS, EX_D_BIG = 6, EX_D_SMALL = PCSEG_EX_SMALL_D;
+static_assert((EX_LDS_SMALL & (EX_LDS_SMALL - 1)) == 0 && EX_LDS_SMALL >= (2 << EX_D_SMALL), "the first window must fit the LDS share");
 
 struct ExactHeap {
     unsigned long long *lk;  // LDS keys   (slot d at lk[d], slot 0 unused)
@@ -1229,8 +1236,15 @@ __device__ __forceinline__ void ex_children(const ExactHeap &h, long long d, uns
     }
 }
 
+// D = levels a sift-down window spans; node r of the window's 2^D - 1 belongs to lane r % 64 (D = 6: one node per lane).
+// A deeper window saves memory round trips and loads more entries that are not on the path; a shallower one the
+// reverse.  Quantised benchmark frames (heaps of 2^16..2^17 entries), 1024 frames per call, Mpixels/s: D = 3 (LDS 2^10)
+// 271, D = 4 (2^9) 295, D = 5 (2^11) 327, D = 6 (2^7) 324, D = 8 (2^9: the whole heap in two windows) 213 -- the
+// memory system is loaded by the entries as much as the waves wait for them, and 6 stays (PCSEG_EX_SMALL_D / _LDS).
+template <int D>
 __device__ __forceinline__ void ex_pop(ExactHeap &h)
 {
+    constexpr int SLOTS = ((1 << D) - 1 + 63) / 64;
     asm volatile("" ::: "memory");
     const int t = threadIdx.x;
     if (--h.items == 0) return;
@@ -1238,31 +1252,54 @@ __device__ __forceinline__ void ex_pop(ExactHeap &h)
     const unsigned idx = h.tail_idx;
     int j = 1;  // slot of the hole
     for (;;) {
-        const long long d = t >= 1 ? ex_slot(j, t) : (long long)h.items + 1;
-        unsigned long long lkey, rkey;
-        unsigned lidx, ridx;
-        if (j < h.lds / 64) ex_children<true>(h, d, lkey, rkey, lidx, ridx);
-        else ex_children<false>(h, d, lkey, rkey, lidx, ridx);
-        // which child would move into this node if the key being placed arrived here
-        int next = 0;
-        unsigned long long sk = key;
-        unsigned sx = 0;
-        if (lkey < sk) { next = 2 * t; sk = lkey; sx = lidx; }
-        if (rkey < sk) { next = 2 * t + 1; sk = rkey; sx = ridx; }
-        // follow the path from the hole (six hops at most) and collect the lanes on it
-        unsigned long long on_path = 0;
+        long long d[SLOTS];
+        unsigned long long lkey[SLOTS], rkey[SLOTS];
+        unsigned lidx[SLOTS], ridx[SLOTS];
+        const bool from_lds = j < (h.lds >> D);  // block-uniform: a window is read from one place
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const int rel = t + 64 * k;
+            d[k] = (rel >= 1 && rel < (1 << D)) ? ex_slot(j, rel) : (long long)h.items + 1;
+            if (from_lds) ex_children<true>(h, d[k], lkey[k], rkey[k], lidx[k], ridx[k]);
+            else ex_children<false>(h, d[k], lkey[k], rkey[k], lidx[k], ridx[k]);
+        }
+        // which child would move into a node if the key being placed arrived there
+        int next[SLOTS];
+        unsigned long long sk[SLOTS];
+        unsigned sx[SLOTS];
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const int rel = t + 64 * k;
+            next[k] = 0;
+            sk[k] = key;
+            sx[k] = 0;
+            if (lkey[k] < sk[k]) { next[k] = 2 * rel; sk[k] = lkey[k]; sx[k] = lidx[k]; }
+            if (rkey[k] < sk[k]) { next[k] = 2 * rel + 1; sk[k] = rkey[k]; sx[k] = ridx[k]; }
+        }
+        // follow the path from the hole (D hops at most) and collect the nodes on it
+        unsigned long long on_path[SLOTS];
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) on_path[k] = 0;
         int rel = 1;
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            const int nx = (int)lane_u32((unsigned)next, rel);
+        for (int s = 0; s < D; ++s) {
+            const int kk = rel >> 6, ll = rel & 63;  // wave-uniform
+            int nx = (int)lane_u32((unsigned)next[0], ll);
+#pragma unroll
+            for (int k = 1; k < SLOTS; ++k)
+                if (kk == k) nx = (int)lane_u32((unsigned)next[k], ll);
             if (nx == 0) break;
-            on_path |= 1ull << rel;
+#pragma unroll
+            for (int k = 0; k < SLOTS; ++k)
+                if (kk == k) on_path[k] |= 1ull << ll;
             rel = nx;
         }
-        if ((on_path >> t) & 1) h.put((int)d, sk, sx);
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+            if ((on_path[k] >> t) & 1) h.put((int)d[k], sk[k], sx[k]);
         asm volatile("" ::: "memory");
         j = (int)ex_slot(j, rel);
-        if (rel < 64 || 2 * (long long)j > h.items) break;
+        if (rel < (1 << D) || 2 * (long long)j > h.items) break;
     }
     if (t == 0) h.put(j, key, idx);
     asm volatile("" ::: "memory");
@@ -1282,7 +1319,7 @@ __global__ void __launch_bounds__(256) ws_exact_init_kernel(const int *__restric
         out[base + i] = mask[base + i] ? markers[base + i] : 0;
 }
 
-template <int EX_LDS>
+template <int EX_LDS, int D>
 __global__ void __launch_bounds__(64) ws_exact_kernel(const unsigned *__restrict__ val, const int *__restrict__ markers,
                                                        const uint8_t *__restrict__ mask, int *__restrict__ out,
                                                        const int *__restrict__ flags, unsigned long long *__restrict__ heap_key,
@@ -1328,7 +1365,7 @@ __global__ void __launch_bounds__(64) ws_exact_kernel(const unsigned *__restrict
             open = in_mask != 0 && taken == 0;
         }
         const int lab = o[(int64_t)r0 * W + c0];
-        ex_pop(h);
+        ex_pop<D>(h);
         unsigned long long m = __ballot(open);
         while (m) {
             const int l = __ffsll((long long)m) - 1;
@@ -1612,9 +1649,9 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
         if (B <= ncu)
-            PCSEG_LAUNCH(ws_exact_kernel<EX_LDS_BIG>, dim3(B), dim3(64), 0, s, val, markers, mask, out, flags2, heap_key, heap_idx, H, W);
+            PCSEG_LAUNCH((ws_exact_kernel<EX_LDS_BIG, EX_D_BIG>), dim3(B), dim3(64), 0, s, val, markers, mask, out, flags2, heap_key, heap_idx, H, W);
         else
-            PCSEG_LAUNCH(ws_exact_kernel<EX_LDS_SMALL>, dim3(B), dim3(64), 0, s, val, markers, mask, out, flags2, heap_key, heap_idx, H, W);
+            PCSEG_LAUNCH((ws_exact_kernel<EX_LDS_SMALL, EX_D_SMALL>), dim3(B), dim3(64), 0, s, val, markers, mask, out, flags2, heap_key, heap_idx, H, W);
         PCSEG_CHECK_LAUNCH();
     }
     if (unsigned long long *dev_tiles = ws_dev_tiles()) {
