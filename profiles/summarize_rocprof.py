@@ -73,14 +73,15 @@ def main(src, tag, here=None):
                 b = (2 * fpl + wpl) * 1024
                 w.writerow([k, max(fc, wc), round(fpl, 1), round(wpl, 1), int(b)])
                 traffic[k.split("<")[0]] = traffic.get(k.split("<")[0], 0) + 0  # placeholder to keep key order
-            # bench.py keys by bare kernel name; for templated kernels keep the instantiation with most launches
+            # bench.py keys by bare kernel name; for templated kernels keep the instantiation that moves the most bytes in all
             best = {}
             for k in names:
                 base = k.split("<")[0]
                 fc, fv = pmc.get("FETCH_SIZE", {}).get(k, [0, 0.0])
                 wc, wv = pmc.get("WRITE_SIZE", {}).get(k, [0, 0.0])
-                if fc >= best.get(base, (0, 0))[0]:
-                    best[base] = (fc, int((2 * (fv / fc if fc else 0) + (wv / wc if wc else 0)) * 1024))
+                per_launch = int((2 * (fv / fc if fc else 0) + (wv / wc if wc else 0)) * 1024)
+                if per_launch * max(fc, wc) >= best.get(base, (0, 0))[0]:
+                    best[base] = (per_launch * max(fc, wc), per_launch)
             traffic = {k: v[1] for k, v in best.items()}
         json.dump(traffic, open(os.path.join(here, "traffic.json"), "w"), indent=1, sort_keys=True)
         # whole chain per step: every kernel's launches x bytes; the number of steps in the PMC run = launches of the
