@@ -826,9 +826,13 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
 }
 
 // UF_OPTIMISTIC over whole frames with W % 4 == 0: four pixels per lane (16-byte parent / label accesses; neighbours
-// mostly share their root, so the walk is repeated only when the parent entry changes)
-__global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict__ parent, int *__restrict__ F, uint8_t *__restrict__ bad,
-                                                            int *__restrict__ tie_flags, int64_t n)
+// mostly share their root, so the walk is repeated only when the parent entry changes).  The label image is WRITTEN
+// but not read: a reachable pixel whose minimum-neighbour mask is 0 is a seed (ws_uf_tile_frame; every other reachable
+// pixel got its level from a neighbour), only seeds carry a label before this pass, and only their four bytes are
+// fetched -- 1 byte of mask per pixel instead of 4 of labels.
+__global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ minmask,
+                                                            int *__restrict__ F, uint8_t *__restrict__ bad, int *__restrict__ tie_flags,
+                                                            int64_t n)
 {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int b = blockIdx.y;
@@ -836,15 +840,17 @@ __global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict
     const int64_t fbase = (int64_t)b * n;
     const int *par = parent + fbase;
     const int4 p4 = *reinterpret_cast<const int4 *>(par + i);
-    int4 f4 = *reinterpret_cast<const int4 *>(F + fbase + i);
+    const unsigned m4 = *reinterpret_cast<const unsigned *>(minmask + fbase + i);
     const int pv[4] = {p4.x, p4.y, p4.z, p4.w};
-    int fv[4] = {f4.x, f4.y, f4.z, f4.w};
+    int fv[4] = {0, 0, 0, 0};  // unreachable pixels and pixels of components without a seed stay unlabelled
     int last_p = -1, last_root = -1, last_lab = 0;
     bool wrote = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int x = pv[j];
         if (x < 0) continue;
+        const bool seed = ((m4 >> (8 * j)) & 255u) == 0;
+        if (seed) fv[j] = F[fbase + i + j];
         if (x != last_p) {
             last_p = x;
             int q;
@@ -853,7 +859,7 @@ __global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict
             last_lab = x < UF_NS ? F[fbase + x] : 0;  // roots are labelled pixels, never changed by this pass
         }
         if (last_root >= UF_NS) continue;  // no labelled pixel in the component
-        if (fv[j] == 0) {
+        if (!seed) {
             fv[j] = last_lab;
             wrote = true;
         } else if (fv[j] != last_lab) {
@@ -1559,9 +1565,10 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                              tilesX, tilesY);
                 PCSEG_CHECK_LAUNCH();
             }
-            if (first_level && act == nullptr && flist == nullptr && (W & 3) == 0 && ((uintptr_t)out & 15) == 0) {
+            if (first_level && act == nullptr && flist == nullptr && (W & 3) == 0 && (((uintptr_t)out | (uintptr_t)uf_parent) & 15) == 0 &&
+                ((uintptr_t)uf_mask & 3) == 0) {
                 PCSEG_LAUNCH(ws_uf_label4_kernel, dim3((unsigned)((npx / 4 + 255) / 256), B), dim3(256), 0, s,
-                             (const int *)uf_parent, out, uf_bad1, out_flags, npx);
+                             (const int *)uf_parent, (const uint8_t *)uf_mask, out, uf_bad1, out_flags, npx);
                 PCSEG_CHECK_LAUNCH();
             } else if (first_level) {
                 PCSEG_LAUNCH(ws_uf_label_kernel<UF_OPTIMISTIC>, lgrid, dim3(256), 0, s, flist, (const int *)uf_parent, out, act,
