@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = 2 per core)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event table to stderr")
-    ap.add_argument("--lanes", type=int, default=3,
+    ap.add_argument("--lanes", type=int, default=8,
                     help="host threads (each with its own stream pair) that consecutive batches alternate between")
     ap.add_argument("--single-class-stream", action="store_true",
                     help="A/B aid: merges and particle fill on the class-map stream instead of streams of their own")

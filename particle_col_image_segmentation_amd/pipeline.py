@@ -159,7 +159,7 @@ def _on(stream, *tensors):
 
 class FramePipeline:
     def __init__(self, cell_types=None, threshold=0.5, boundary_plane=BOUNDARY_PLANE, cap=None, merged=True,
-                 watershed_mode=0, overlap=True, lanes=3, multi_stream=True):
+                 watershed_mode=0, overlap=True, lanes=8, multi_stream=True):
         self.cell_types = dict(cell_types or CELL_TYPES_5)
         self.tables_ = ops.ClassTables(self.cell_types, ta.CELL_TYPES, ta.MIN_CELL_AREA, ta.MIN_CLUSTER_AREA)
         self.threshold = float(threshold)

@@ -153,7 +153,7 @@ def test_batches_in_flight_do_not_interfere():
     from particle_col_image_segmentation_amd.pipeline import FramePipeline
     ct = dict(synth.CELL_TYPES_5)
     batches = [torch.from_numpy(synth.gen_batch(7000 + 10 * k, 6, 192, 256, ties=(k % 3 == 2))).cuda() for k in range(6)]
-    pipe = FramePipeline(ct)
+    pipe = FramePipeline(ct, lanes=2)
     in_flight = [pipe.run(st) for st in batches]
     solo = FramePipeline(ct, overlap=False)
     keys = ("denoised", "labels", "counts", "stats", "recreated", "overlap_area", "markers", "n_markers", "ws_labels",
