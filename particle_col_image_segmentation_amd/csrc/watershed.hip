@@ -133,12 +133,18 @@ __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__res
 // 16-wave barriers, the shifted tiling has 81 tiles per 1024^2 frame instead of 64 (+27 %) where 64-tiles have 289
 // instead of 256 (+13 %), and the number of rounds hardly drops because levels travel along winding paths, not tile
 // diameters.
+#ifndef PCSEG_WS_FSM
+#define PCSEG_WS_FSM 0  // 1: quadrant (raster-order wavefront) sweeps, 0: line sweeps -- see ws_quadrant_sweep
+#endif
 template <int T>
 struct RelaxGeom {
     static_assert(T == 64 || T == 128, "relaxation tiles are 64 or 128 pixels wide");
     static constexpr int S = T + 2;        // with halo
-    static constexpr int P = T + 3;        // LDS row pitch in elements (odd)
-    static constexpr int N = S * P;        // LDS elements
+    // LDS row pitch in elements.  Line sweeps (one row or column per lane) want it odd; the wavefront sweeps of the
+    // quadrant scheme walk lane l along row l at column (step - l), i.e. lanes are P - 1 or P + 1 elements apart: even P
+    static constexpr int P = (PCSEG_WS_FSM && T == 64) ? T + 4 : T + 3;
+    static constexpr int PAD = 8;          // elements in front of and behind the tile (wavefront lanes read past their row's ends)
+    static constexpr int N = S * P + 2 * PAD;  // LDS elements
     static constexpr int G = T / 64;       // 64-line groups per direction, and 64-cell segments per line
     static constexpr int THREADS = 4 * G * G * 64;  // one wave per (direction, line group, segment)
     static constexpr int HE = T / 2;       // cells of a half edge
@@ -218,6 +224,77 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
             // the cell since the batch was read
 #pragma unroll
             for (int j = 0; j < WS_BATCH; ++j) atomicMin(&sLw[2 * (base + j * STEP)], nw[j]);
+            diff |= batch_diff;
+        }
+    }
+    return diff != 0;
+}
+
+// QUADRANT SWEEPS (fast-sweeping order) -- built, bit-exact on every test, NOT the default (PCSEG_WS_FSM).  A line sweep
+// carries a level along one axis only, so a minimax path that turns costs an iteration per turn -- and the paths of a
+// noisy probability map turn every few pixels: isolated 64 x 64 tiles of the benchmark frames need 14 iterations of the
+// four line sweeps on average (35 at worst).  A raster-order Gauss-Seidel sweep
+//     L(r, c) = min(L(r, c), max(value(r, c), min(L(r - dr, c), L(r, c - dc))))   rows in direction dr, columns in dc
+// carries a level along ANY path that is monotone in both axes, so what counts is the number of QUADRANT changes of a
+// path: 3.6 iterations on average, 7 at worst (same tiles, same fixed point; numpy simulation).  One wave runs one
+// quadrant as a wavefront: lane l owns row l (from the top for dr > 0, from the bottom otherwise) and is at column
+// (step - l) of it, so the row above is exactly one step ahead and hands its result down through a DPP wave shift -- no
+// LDS read for either neighbour; the left neighbour is the lane's own previous result.  Per batch of 8 steps: the lane's
+// 8 own cells (hand-written ds_read_b64, see ws_sweep), one read of the halo-row cells that lane 0 needs (lane k fetches
+// the cell of step k), and the atomics of the cells that were lowered.
+// MEASURED: an iteration costs 3.9 x one of line sweeps (180 against 46 us over the 16384 tiles of the benchmark batch:
+// 127 steps with half of the lane-steps idle, ten VALU operations on each step's dependency chain against three), which
+// eats the 3.9 x fewer iterations of round 0 (899 against 742 us with a limit of 5 iterations) and loses in the later
+// rounds, where most visits need one or two iterations whatever the sweep: 2.76 ms of relaxation per step against
+// 2.0.  What would make it pay: two quadrants chained per wave (all lanes busy after the ramp) and the activity selects
+// replaced by sentinel cells in a skewed LDS image (64 KB per tile).
+template <int DR, int DC, int P>
+__device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
+{
+    unsigned *sLw = reinterpret_cast<unsigned *>(sLV);
+    const int lr = DR > 0 ? lane + 1 : WS_T - lane;  // the lane's row (LDS coordinates: 1 .. 64)
+    const int hr = DR > 0 ? 0 : WS_T + 1;            // halo row in front of lane 0
+    unsigned left = sLV[lr * P + (DC > 0 ? 0 : WS_T + 1)].x;  // halo cell in front of the row; then the previous result
+    unsigned prev = WS_INF;                                    // result of the previous step (the next lane's `up`)
+    unsigned diff = 0;
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+#pragma unroll 1
+    for (int j0 = 0; j0 < 2 * WS_T; j0 += 8) {
+        // cell of step j: column 1 + t or 64 - t with t = j - lane (outside 0 .. 63: not this lane's turn; the address
+        // then lies in a neighbouring row or the pad, the value is ignored and the atomic gets +inf)
+        const int t0 = j0 - lane;
+        const int first = lr * P + (DC > 0 ? 1 + t0 : WS_T - t0);     // element of the batch's first step
+        const int low = DC > 0 ? first : first - 7;                   // lowest element of the batch
+        const unsigned addr = (unsigned)(uintptr_t)(sLV + low);
+        u2v t[8];
+#define PCSEG_DS_READ(j) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t[j]) : "v"(addr), "n"(8 * (DC > 0 ? (j) : 7 - (j))))
+        PCSEG_DS_READ(0); PCSEG_DS_READ(1); PCSEG_DS_READ(2); PCSEG_DS_READ(3);
+        PCSEG_DS_READ(4); PCSEG_DS_READ(5); PCSEG_DS_READ(6); PCSEG_DS_READ(7);
+#undef PCSEG_DS_READ
+        // halo-row cell above (below) lane 0's cell of step j0 + k, fetched by lane k (lane 0 is at column t = j)
+        const int hk = min(j0 + min(lane, 7), WS_T - 1);
+        const unsigned hv = sLw[2 * (hr * P + (DC > 0 ? 1 + hk : WS_T - hk))];
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+        unsigned wr[8];
+        unsigned batch_diff = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool act = (unsigned)(t0 + k) < (unsigned)WS_T;
+            const unsigned h = (unsigned)__builtin_amdgcn_readlane((int)hv, k);
+            // lane l takes lane l - 1's result of the previous step; lane 0 the halo cell (wave_shr:1, `old` where no source)
+            const unsigned up = (unsigned)__builtin_amdgcn_update_dpp((int)h, (int)prev, 0x138, 0xF, 0xF, false);
+            const unsigned cur = t[k].x, v = t[k].y;
+            const unsigned m = min(up, left);
+            const unsigned cand = min(max(v, m), max(min(v, m), cur));  // median(value, m, cur) = min(cur, max(value, m))
+            const unsigned nw = act ? cand : left;  // a lane that has not started keeps its halo cell as `left`
+            wr[k] = act ? cand : WS_INF;
+            batch_diff |= act ? (cur ^ cand) : 0u;
+            left = nw;
+            prev = nw;
+        }
+        if (__any(batch_diff != 0)) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) atomicMin(&sLw[2 * (first + DC * k)], wr[k]);
             diff |= batch_diff;
         }
     }
@@ -410,10 +487,17 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
         // one code path per direction: the step is a compile-time constant there, so the LDS addresses of a batch are
         // base + constant
         bool changed;
-        if (dir == 0) changed = ws_sweep<1>(sLV, start);
-        else if (dir == 1) changed = ws_sweep<-1>(sLV, start);
-        else if (dir == 2) changed = ws_sweep<P>(sLV, start);
-        else changed = ws_sweep<-P>(sLV, start);
+        if constexpr (PCSEG_WS_FSM && T == 64) {
+            if (dir == 0) changed = ws_quadrant_sweep<1, 1, P>(sLV, lane);
+            else if (dir == 1) changed = ws_quadrant_sweep<1, -1, P>(sLV, lane);
+            else if (dir == 2) changed = ws_quadrant_sweep<-1, 1, P>(sLV, lane);
+            else changed = ws_quadrant_sweep<-1, -1, P>(sLV, lane);
+        } else {
+            if (dir == 0) changed = ws_sweep<1>(sLV, start);
+            else if (dir == 1) changed = ws_sweep<-1>(sLV, start);
+            else if (dir == 2) changed = ws_sweep<P>(sLV, start);
+            else changed = ws_sweep<-P>(sLV, start);
+        }
         if (!__syncthreads_or(changed)) { capped = false; break; }
         changed_any = true;
     }
@@ -462,7 +546,8 @@ __global__ void __launch_bounds__(RelaxGeom<T>::THREADS) ws_relax_kernel(WsInput
 {
     extern __shared__ __attribute__((aligned(16))) uint2 relax_lds[];  // RelaxGeom<T>::N cells
     const TileIndex t = xcd_tile_index();  // a tile's halo is its neighbours' rim: keep them on one XCD's L2
-    ws_relax_tile<T>(relax_lds, in, FIRST, val, L, dirty_in, dirty_out, any_changed, H, W, cur, nxt, max_iter, t.x, t.y, t.z);
+    ws_relax_tile<T>(relax_lds + RelaxGeom<T>::PAD, in, FIRST, val, L, dirty_in, dirty_out, any_changed, H, W, cur, nxt, max_iter, t.x, t.y,
+                     t.z);
 }
 
 // The fixed point is driven WITHOUT the host: a fixed number of grid rounds is enqueued (a round whose tiles carry no
@@ -492,7 +577,8 @@ __global__ void __launch_bounds__(RelaxGeom<T>::THREADS) ws_relax_tail_kernel(Ws
             return;
         }
         for (int t = 0; t < ntiles; ++t) {
-            ws_relax_tile<T>(relax_lds, in, false, val, L, din, dout, any_changed, H, W, cur, nxt, 100000, t % cur.nx, t / cur.nx, b);
+            ws_relax_tile<T>(relax_lds + RelaxGeom<T>::PAD, in, false, val, L, din, dout, any_changed, H, W, cur, nxt, 100000, t % cur.nx,
+                             t / cur.nx, b);
             __syncthreads();  // the tile's stores (L, marks) before the next tile loads its halo / the next round scans
         }
         uint8_t *tmp = din; din = dout; dout = tmp;
