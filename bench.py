@@ -106,7 +106,7 @@ def cpu_baseline(res, stack, cell_types, n_frames):
 
 def end_to_end_leg(args, stack, cell_types, pipe, dev, world, kernel_only_mpx):
     """What a dataset run costs beyond the kernels (BASELINE configs 3 / 5 code path, per rank): `distributed.run_sharded`
-    over a dataset of 6 batches per rank (the resident batch stands in for every batch: generation is not what is
+    over a dataset of 2 x lanes batches per rank (the resident batch stands in for every batch: generation is not what is
     measured) = kernel chain + device-side table assembly + table download + the all-gather of every table; and the
     same chain fed over PCIe from pinned host memory through `ingest.FrameUploader` (double-buffered copies on a
     stream of their own).  Neither figure is `value` (inputs resident in HBM, by contract)."""
@@ -114,11 +114,12 @@ def end_to_end_leg(args, stack, cell_types, pipe, dev, world, kernel_only_mpx):
     from particle_col_image_segmentation_amd.distributed import run_sharded
     from particle_col_image_segmentation_amd.ingest import FrameUploader
     B, C, H, W = stack.shape
-    n_batches = 6
+    n_batches = max(6, 2 * max(1, getattr(pipe, "lanes", 1)))  # twice the pipeline's depth: steady state, not ramp
     n_frames = n_batches * B * world
     make_batch = lambda ids: stack[:len(ids)]
-    # warm: sort kernels, and the table buffers of EVERY lane's streams (the caching allocator keeps a pool per stream)
-    run_sharded(B * world * max(1, getattr(pipe, "lanes", 1)), make_batch, pipe, batch=B, device=dev, check=False)
+    # warm with a dataset of the same size: sort kernels, the table buffers of every lane's streams (the caching allocator
+    # keeps a pool per stream) and the pinned staging buffers of the download (page-locking 270 MB costs 30 ms once)
+    run_sharded(n_frames, make_batch, pipe, batch=B, device=dev, check=False)
     pipe.synchronize()
     t0 = time.perf_counter()
     tabs = run_sharded(n_frames, make_batch, pipe, batch=B, device=dev, check=False)

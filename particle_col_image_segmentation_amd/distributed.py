@@ -5,6 +5,8 @@ state, so the path shards with NO data-path collective.  The only exchange is th
 table: row counts first, then one padded ``all_gather`` -- ``nccl`` (= RCCL over xGMI) for
 CUDA tensors, ``gloo`` for CPU tensors (tests).  Label masks stay on the rank that made them.
 """
+import collections
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -72,7 +74,8 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
     frames written by ``split_zstack.process_tif`` through ``ingest.FrameUploader``).
 
     Per batch only the device-side table assembly runs (``pipe.tables_device``: three kernels and one 24-byte read),
-    and only after the NEXT batch has been handed to the pipeline, so it sits under that batch's kernels.  The per-batch
+    and only after ``pipe.lanes`` NEWER batches have been handed to the pipeline, so the wait for the batch is short and
+    the assembly sits under the newer batches' kernels.  The per-batch
     device tables are concatenated, all-gathered as device tensors (RCCL when the group is NCCL) and downloaded ONCE;
     the host epilogue (``pipe.host_tables``) then runs on the gathered rows.  A rank that owns no frame
     (``n_frames < world``) contributes ``pipe.empty_device_tables``, so that every rank enters the same collectives with
@@ -82,15 +85,17 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
     mine = shard_frames(n_frames, rank, world)
     ratio_kw = {"ratios": table_kwargs["ratios"]} if "ratios" in table_kwargs else {}
     parts = []
-    pending = None
-    for i in range(0, len(mine), batch):
+    pending = collections.deque()
+    depth = max(1, int(getattr(pipe, "lanes", 1)))  # batches the pipeline keeps in flight: a table is assembled (which
+    for i in range(0, len(mine), batch):            # waits for its batch) only once that many newer batches are queued
         ids = mine[i:i + batch]
-        res = pipe.run(make_batch(ids))
-        if pending is not None:
-            parts.append(pipe.tables_device(pending[0], frame_ids=pending[1], check=check, **ratio_kw))
-        pending = (res, ids)
-    if pending is not None:
-        parts.append(pipe.tables_device(pending[0], frame_ids=pending[1], check=check, **ratio_kw))
+        pending.append((pipe.run(make_batch(ids)), ids))
+        if len(pending) > depth:
+            res, rid = pending.popleft()
+            parts.append(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
+    while pending:
+        res, rid = pending.popleft()
+        parts.append(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
     if parts:
         merged = {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
     else:

@@ -387,14 +387,16 @@ class FramePipeline:
         rec = host["frames_rec"]
         px2 = ta.PX_TO_UM_CONV ** 2
         frame_rows = []
-        for row_rec in rec:
-            row = [float(v) for v in row_rec[:6]]
-            pa_um = float(row_rec[3]) / px2
-            for s in range(len(tb.slot_names)):
-                present, count, area_px = (int(v) for v in row_rec[6 + 3 * s: 9 + 3 * s])
-                dens = round(count / pa_um, 5) if present and pa_um else float("nan")
-                ratio = round((area_px / px2) / pa_um, 5) if present and pa_um else float("nan")
-                row += [float(present), float(count), dens, ratio]
+        n_slots = len(tb.slot_names)
+        nan = float("nan")
+        for row_rec in rec.tolist():  # plain Python floats: indexing numpy scalars one by one cost 50 us per frame
+            row = row_rec[:6]
+            pa_um = row_rec[3] / px2
+            for s in range(n_slots):
+                present, count, area_px = int(row_rec[6 + 3 * s]), int(row_rec[7 + 3 * s]), int(row_rec[8 + 3 * s])
+                ok = present and pa_um
+                row += [float(present), float(count), round(count / pa_um, 5) if ok else nan,
+                        round((area_px / px2) / pa_um, 5) if ok else nan]
             frame_rows.append(row)
         out["frames"] = np.array(frame_rows, np.float64).reshape(len(frame_rows), len(cols["frames"]))
         dist_rows = []
