@@ -134,7 +134,7 @@ __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__res
 // instead of 256 (+13 %), and the number of rounds hardly drops because levels travel along winding paths, not tile
 // diameters.
 #ifndef PCSEG_WS_FSM
-#define PCSEG_WS_FSM 0  // 1: quadrant (raster-order wavefront) sweeps, 0: line sweeps -- see ws_quadrant_sweep
+#define PCSEG_WS_FSM 1  // 1: quadrant (raster-order wavefront) sweeps, 0: line sweeps -- see ws_quadrant_sweep
 #endif
 template <int T>
 struct RelaxGeom {
@@ -230,71 +230,91 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
     return diff != 0;
 }
 
-// QUADRANT SWEEPS (fast-sweeping order) -- built, bit-exact on every test, NOT the default (PCSEG_WS_FSM).  A line sweep
-// carries a level along one axis only, so a minimax path that turns costs an iteration per turn -- and the paths of a
-// noisy probability map turn every few pixels: isolated 64 x 64 tiles of the benchmark frames need 14 iterations of the
-// four line sweeps on average (35 at worst).  A raster-order Gauss-Seidel sweep
+// QUADRANT SWEEPS (fast-sweeping order; PCSEG_WS_FSM, the default).  A line sweep carries a level along one axis only,
+// so a minimax path that turns costs an iteration per turn -- and the paths of a noisy probability map turn every few
+// pixels: isolated 64 x 64 tiles of the benchmark frames need 14 iterations of the four line sweeps on average (35 at
+// worst).  A raster-order Gauss-Seidel sweep
 //     L(r, c) = min(L(r, c), max(value(r, c), min(L(r - dr, c), L(r, c - dc))))   rows in direction dr, columns in dc
 // carries a level along ANY path that is monotone in both axes, so what counts is the number of QUADRANT changes of a
-// path: 3.6 iterations on average, 7 at worst (same tiles, same fixed point; numpy simulation).  One wave runs one
-// quadrant as a wavefront: lane l owns row l (from the top for dr > 0, from the bottom otherwise) and is at column
-// (step - l) of it, so the row above is exactly one step ahead and hands its result down through a DPP wave shift -- no
-// LDS read for either neighbour; the left neighbour is the lane's own previous result.  Per batch of 8 steps: the lane's
-// 8 own cells (hand-written ds_read_b64, see ws_sweep), one read of the halo-row cells that lane 0 needs (lane k fetches
-// the cell of step k), and the atomics of the cells that were lowered.
-// MEASURED: an iteration costs 3.9 x one of line sweeps (180 against 46 us over the 16384 tiles of the benchmark batch:
-// 127 steps with half of the lane-steps idle, ten VALU operations on each step's dependency chain against three), which
-// eats the 3.9 x fewer iterations of round 0 (899 against 742 us with a limit of 5 iterations) and loses in the later
-// rounds, where most visits need one or two iterations whatever the sweep: 2.76 ms of relaxation per step against
-// 2.0.  What would make it pay: two quadrants chained per wave (all lanes busy after the ramp) and the activity selects
-// replaced by sentinel cells in a skewed LDS image (64 KB per tile).
+// path: 3.6 iterations on average, 7 at worst; over a whole frame and all rounds 2951 tile-iterations instead of 7751
+// (numpy simulation of the round structure, same fixed point).  One wave runs one quadrant as a wavefront: lane l owns
+// row l (from the top for dr > 0, from the bottom otherwise), the row above is exactly one step ahead on the same column
+// and hands its result down through a DPP wave shift -- no LDS read for either neighbour; the left neighbour is the
+// lane's own previous result.
+// History: the plain wavefront (lane l at column step - l, 127 steps, half of the lane-steps idle, activity selects
+// on every step) cost 3.9 x a line iteration and lost (2.76 ms of relaxation per step against 2.0).  The CYCLIC
+// wavefront below keeps all lanes busy for exactly 64 steps and costs 2.4 x: 1.62 ms per step (rounds 557 / 460 / 287 /
+// 172 us against 742 / 606 / 327 / 175).
 template <int DR, int DC, int P>
 __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
 {
+    // CYCLIC wavefront: lane l owns row l and is at cyclic position u = (step - l) mod 64 of it (column u for dc > 0,
+    // 63 - u otherwise), so all 64 lanes work in all 64 steps.  The row above is still exactly one step ahead on the
+    // same column; a row is swept from wherever its lane starts to its end and then from its beginning -- a valid
+    // Gauss-Seidel order (2.5 x fewer tile-iterations than line sweeps in the whole-frame simulation, against 2.6 x for
+    // the pure raster order).  At u == 0 the running value restarts from the halo cell in front of the row.
     unsigned *sLw = reinterpret_cast<unsigned *>(sLV);
-    const int lr = DR > 0 ? lane + 1 : WS_T - lane;  // the lane's row (LDS coordinates: 1 .. 64)
-    const int hr = DR > 0 ? 0 : WS_T + 1;            // halo row in front of lane 0
-    unsigned left = sLV[lr * P + (DC > 0 ? 0 : WS_T + 1)].x;  // halo cell in front of the row; then the previous result
-    unsigned prev = WS_INF;                                    // result of the previous step (the next lane's `up`)
-    unsigned diff = 0;
     typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    unsigned diff = 0;
+    {   // the first row takes the halo row's levels before the sweep (lane = column): lane 0 then needs no `up`
+        constexpr int fr = DR > 0 ? 1 : WS_T, hr = DR > 0 ? 0 : WS_T + 1;
+        const uint2 c = sLV[fr * P + 1 + lane];
+        const unsigned h = sLV[hr * P + 1 + lane].x;
+        const unsigned nw = min(c.x, max(c.y, h));
+        atomicMin(&sLw[2 * (fr * P + 1 + lane)], nw);
+        diff |= nw ^ c.x;
+    }
+    const int lr = DR > 0 ? lane + 1 : WS_T - lane;  // the lane's row (LDS coordinates 1 .. 64)
+    const uint2 *row = sLV + lr * P;
+    const unsigned halo = row[DC > 0 ? 0 : WS_T + 1].x;
+    const int u0 = (0 - lane) & 63;                   // cyclic position at step 0
+    // what the first step finds behind it: the row's cell at position u0 - 1 as it is now
+    unsigned left = row[DC > 0 ? u0 : WS_T + 1 - u0].x;  // (u0 == 0: replaced by the halo cell at the first step anyway)
+    // what the next lane finds above its first cell: this row's cell at THAT lane's first position
+    const int un = (0 - (lane + 1)) & 63;
+    unsigned prev = row[DC > 0 ? 1 + un : WS_T - un].x;
+    // byte address of the row's cell at cyclic position 0, and the step per position
+    const unsigned a0 = (unsigned)(uintptr_t)(row + (DC > 0 ? 1 : WS_T));
 #pragma unroll 1
-    for (int j0 = 0; j0 < 2 * WS_T; j0 += 8) {
-        // cell of step j: column 1 + t or 64 - t with t = j - lane (outside 0 .. 63: not this lane's turn; the address
-        // then lies in a neighbouring row or the pad, the value is ignored and the atomic gets +inf)
-        const int t0 = j0 - lane;
-        const int first = lr * P + (DC > 0 ? 1 + t0 : WS_T - t0);     // element of the batch's first step
-        const int low = DC > 0 ? first : first - 7;                   // lowest element of the batch
-        const unsigned addr = (unsigned)(uintptr_t)(sLV + low);
+    for (int j0 = 0; j0 < WS_T; j0 += 8) {
+        const int ub = (u0 + j0) & 63;
+        const int wrap = 64 - ub;       // steps of this batch from which on the lane has wrapped (1 .. 64; >= 8: none)
+        const int wk = wrap & 63;       // the step at which the lane is AT position 0 (ub == 0: the first)
+        // step k reads position ub + k, 64 positions (512 bytes) back once the lane has wrapped: one of two bases picked
+        // per step, the step itself as the instruction's offset (counted from the batch's lowest address for dc < 0)
+        const unsigned base_a = DC > 0 ? a0 + 8u * (unsigned)ub : a0 - 8u * (unsigned)ub - 56u;
+        const unsigned base_b = DC > 0 ? base_a - 512u : base_a + 512u;
         u2v t[8];
-#define PCSEG_DS_READ(j) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t[j]) : "v"(addr), "n"(8 * (DC > 0 ? (j) : 7 - (j))))
-        PCSEG_DS_READ(0); PCSEG_DS_READ(1); PCSEG_DS_READ(2); PCSEG_DS_READ(3);
-        PCSEG_DS_READ(4); PCSEG_DS_READ(5); PCSEG_DS_READ(6); PCSEG_DS_READ(7);
+#define PCSEG_DS_READ(k)                                                                                         \
+        {                                                                                                            \
+            const unsigned ba = (k) >= wrap ? base_b : base_a;                                                         \
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t[k]) : "v"(ba), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k)))); \
+        }
+        PCSEG_DS_READ(0) PCSEG_DS_READ(1) PCSEG_DS_READ(2) PCSEG_DS_READ(3)
+        PCSEG_DS_READ(4) PCSEG_DS_READ(5) PCSEG_DS_READ(6) PCSEG_DS_READ(7)
 #undef PCSEG_DS_READ
-        // halo-row cell above (below) lane 0's cell of step j0 + k, fetched by lane k (lane 0 is at column t = j)
-        const int hk = min(j0 + min(lane, 7), WS_T - 1);
-        const unsigned hv = sLw[2 * (hr * P + (DC > 0 ? 1 + hk : WS_T - hk))];
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
         unsigned wr[8];
         unsigned batch_diff = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const bool act = (unsigned)(t0 + k) < (unsigned)WS_T;
-            const unsigned h = (unsigned)__builtin_amdgcn_readlane((int)hv, k);
-            // lane l takes lane l - 1's result of the previous step; lane 0 the halo cell (wave_shr:1, `old` where no source)
-            const unsigned up = (unsigned)__builtin_amdgcn_update_dpp((int)h, (int)prev, 0x138, 0xF, 0xF, false);
+            // lane l takes lane l - 1's result of the previous step; lane 0 has no row above (wave_shr:1, `old` = +inf)
+            const unsigned up = (unsigned)__builtin_amdgcn_update_dpp((int)WS_INF, (int)prev, 0x138, 0xF, 0xF, false);
+            const unsigned lf = wk == k ? halo : left;
             const unsigned cur = t[k].x, v = t[k].y;
-            const unsigned m = min(up, left);
+            const unsigned m = min(up, lf);
             const unsigned cand = min(max(v, m), max(min(v, m), cur));  // median(value, m, cur) = min(cur, max(value, m))
-            const unsigned nw = act ? cand : left;  // a lane that has not started keeps its halo cell as `left`
-            wr[k] = act ? cand : WS_INF;
-            batch_diff |= act ? (cur ^ cand) : 0u;
-            left = nw;
-            prev = nw;
+            wr[k] = cand;
+            batch_diff |= cur ^ cand;
+            left = cand;
+            prev = cand;
         }
         if (__any(batch_diff != 0)) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) atomicMin(&sLw[2 * (first + DC * k)], wr[k]);
+            for (int k = 0; k < 8; ++k) {
+                unsigned *cell = reinterpret_cast<unsigned *>(const_cast<uint2 *>(row)) + 2 * (DC > 0 ? 1 + ((ub + k) & 63) : WS_T - ((ub + k) & 63));
+                atomicMin(cell, wr[k]);
+            }
             diff |= batch_diff;
         }
     }
@@ -1474,20 +1494,21 @@ __global__ void __launch_bounds__(64) ws_exact_kernel(const unsigned *__restrict
 
 using namespace pcseg;
 
-// Round 0 stops every tile after this many sweeps per direction: the round after it visits every tile anyway (with the
-// other tiling), so squeezing the last changes out of isolated tiles is wasted work; a tile cut short marks all four
-// corner tiles.  Measured on the benchmark batch: 16 -> 4.6 % less relaxation time than no limit, 8 -> 1 %, 6 -> none.
+// Round 0 stops every tile after this many iterations (one sweep per direction or quadrant each): the round after it
+// visits every tile anyway (with the other tiling), so squeezing the last changes out of isolated tiles is wasted work;
+// a tile cut short marks all four corner tiles.  Later grid rounds have a limit of their own (a tile cut short is
+// finished by its corner tiles or a later round; the per-frame tail kernel has no limit).  Measured on the benchmark
+// batch, relaxation per launch -- line sweeps: round 0 at 16 is 4.6 % better than no limit (8 -> 1 %, 6 -> none), later
+// rounds no limit 179.9 us, 32 -> 177.5, 16 -> 170.5, 8 -> 175.1 plus 122 us of tail kernel; quadrant sweeps (which
+// need about a third of the iterations): 4 / 6 -> 136 us, 3 / 4 -> 134, 5 / 5 -> 137, 4 / 16 -> 139, 16 / 16 -> 154.
+#ifndef PCSEG_WS_ROUND0_SWEEPS
+#define PCSEG_WS_ROUND0_SWEEPS (PCSEG_WS_FSM ? 4 : 16)
+#endif
 #ifndef PCSEG_WS_ROUND_SWEEPS
-// later grid rounds: same limit (a tile cut short marks its four corner tiles and is finished by them or by a later round;
-// the per-frame tail kernel has no limit).  Relaxation per launch on the benchmark batch: no limit 179.9 us, 32 -> 177.5,
-// 16 -> 170.5, 8 -> 175.1 plus 122 us of tail kernel.
-#define PCSEG_WS_ROUND_SWEEPS 16
+#define PCSEG_WS_ROUND_SWEEPS (PCSEG_WS_FSM ? 6 : 16)
 #endif
 #ifndef PCSEG_WS_RELAX_TILE
 #define PCSEG_WS_RELAX_TILE 64
-#endif
-#ifndef PCSEG_WS_ROUND0_SWEEPS
-#define PCSEG_WS_ROUND0_SWEEPS 16
 #endif
 constexpr int WS_ROUND0_SWEEPS = PCSEG_WS_ROUND0_SWEEPS;
 
