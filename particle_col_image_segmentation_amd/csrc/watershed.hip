@@ -278,17 +278,20 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
 #pragma unroll 1
     for (int j0 = 0; j0 < WS_T; j0 += 8) {
         const int ub = (u0 + j0) & 63;
-        const int wrap = 64 - ub;       // steps of this batch from which on the lane has wrapped (1 .. 64; >= 8: none)
-        const int wk = wrap & 63;       // the step at which the lane is AT position 0 (ub == 0: the first)
-        // step k reads position ub + k, 64 positions (512 bytes) back once the lane has wrapped: one of two bases picked
-        // per step, the step itself as the instruction's offset (counted from the batch's lowest address for dc < 0)
+        // Step k reads position ub + k, 64 positions (512 bytes) back once the lane has wrapped: one of two bases, the
+        // step itself as the instruction's offset (counted from the batch's lowest address for dc < 0).  WHICH lanes have
+        // wrapped is wave-uniform knowledge: lane l is at position 0 at step l, so at step k of this batch the wrapped
+        // lanes are j0 + 1 .. j0 + k and the lane at position 0 is j0 + k -- the selects take their condition from a
+        // scalar mask (one VALU operation each, no per-lane compare).
         const unsigned base_a = DC > 0 ? a0 + 8u * (unsigned)ub : a0 - 8u * (unsigned)ub - 56u;
         const unsigned base_b = DC > 0 ? base_a - 512u : base_a + 512u;
+        unsigned ba[8];
         u2v t[8];
-#define PCSEG_DS_READ(k)                                                                                         \
-        {                                                                                                            \
-            const unsigned ba = (k) >= wrap ? base_b : base_a;                                                         \
-            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t[k]) : "v"(ba), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k)))); \
+#define PCSEG_DS_READ(k)                                                                                                   \
+        {                                                                                                                      \
+            const unsigned long long wrapped = (((1ull << (k)) - 1ull) << 1) << j0;  /* lanes j0 + 1 .. j0 + k */              \
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(ba[k]) : "v"(base_a), "v"(base_b), "s"(wrapped));                     \
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t[k]) : "v"(ba[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))));     \
         }
         PCSEG_DS_READ(0) PCSEG_DS_READ(1) PCSEG_DS_READ(2) PCSEG_DS_READ(3)
         PCSEG_DS_READ(4) PCSEG_DS_READ(5) PCSEG_DS_READ(6) PCSEG_DS_READ(7)
@@ -300,7 +303,9 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
         for (int k = 0; k < 8; ++k) {
             // lane l takes lane l - 1's result of the previous step; lane 0 has no row above (wave_shr:1, `old` = +inf)
             const unsigned up = (unsigned)__builtin_amdgcn_update_dpp((int)WS_INF, (int)prev, 0x138, 0xF, 0xF, false);
-            const unsigned lf = wk == k ? halo : left;
+            const unsigned long long at0 = (1ull << k) << j0;  // the lane that is at position 0 now restarts from its halo cell
+            unsigned lf;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lf) : "v"(left), "v"(halo), "s"(at0));
             const unsigned cur = t[k].x, v = t[k].y;
             const unsigned m = min(up, lf);
             const unsigned cand = min(max(v, m), max(min(v, m), cur));  // median(value, m, cur) = min(cur, max(value, m))
@@ -310,11 +315,11 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
             prev = cand;
         }
         if (__any(batch_diff != 0)) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                unsigned *cell = reinterpret_cast<unsigned *>(const_cast<uint2 *>(row)) + 2 * (DC > 0 ? 1 + ((ub + k) & 63) : WS_T - ((ub + k) & 63));
-                atomicMin(cell, wr[k]);
-            }
+            // (the level is the first word of the cell: the read's address and offset serve the atomic as they are)
+#define PCSEG_DS_MIN(k) asm volatile("ds_min_u32 %0, %1 offset:%2" : : "v"(ba[k]), "v"(wr[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
+            PCSEG_DS_MIN(0) PCSEG_DS_MIN(1) PCSEG_DS_MIN(2) PCSEG_DS_MIN(3)
+            PCSEG_DS_MIN(4) PCSEG_DS_MIN(5) PCSEG_DS_MIN(6) PCSEG_DS_MIN(7)
+#undef PCSEG_DS_MIN
             diff |= batch_diff;
         }
     }
