@@ -243,8 +243,9 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
 // lane's own previous result.
 // History: the plain wavefront (lane l at column step - l, 127 steps, half of the lane-steps idle, activity selects
 // on every step) cost 3.9 x a line iteration and lost (2.76 ms of relaxation per step against 2.0).  The CYCLIC
-// wavefront below keeps all lanes busy for exactly 64 steps and costs 2.4 x: 1.62 ms per step (rounds 557 / 460 / 287 /
-// 172 us against 742 / 606 / 327 / 175).
+// wavefront below keeps all lanes busy for exactly 64 steps: 2.4 x and 1.62 ms per step with per-lane compares for
+// the wrap, 2.0 x and 1.34 ms with the selects driven by scalar lane masks and the atomics reusing the read addresses
+// (rounds 377 / 365 / 240 / 144 us against 742 / 606 / 327 / 175).  VALU-bound: six operations per step.
 template <int DR, int DC, int P>
 __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
 {
