@@ -585,8 +585,9 @@ template <int T>
 __global__ void __launch_bounds__(RelaxGeom<T>::THREADS) ws_relax_tail_kernel(WsInputs in, unsigned *__restrict__ val,
                                                                               unsigned *__restrict__ L, uint8_t *__restrict__ dirtyA,
                                                                               uint8_t *__restrict__ dirtyB, int *__restrict__ any_changed,
-                                                                              int *__restrict__ not_converged, int H, int W,
-                                                                              WsTiling t0, WsTiling t1, int first_round, int max_rounds)
+                                                                              int *__restrict__ not_converged, int *__restrict__ exact_flags,
+                                                                              int H, int W, WsTiling t0, WsTiling t1, int first_round,
+                                                                              int max_rounds)
 {
     extern __shared__ __attribute__((aligned(16))) uint2 relax_lds[];
     const int b = blockIdx.x;
@@ -599,7 +600,9 @@ __global__ void __launch_bounds__(RelaxGeom<T>::THREADS) ws_relax_tail_kernel(Ws
         for (int t = threadIdx.x; t < ntiles; t += RelaxGeom<T>::THREADS) any = any || marks[t] != 0;
         if (!__syncthreads_or(any)) return;
         if (round - first_round >= max_rounds) {  // cannot happen for a monotone fixed point; never spin for ever
-            if (threadIdx.x == 0) *not_converged = 1;
+            // L of this frame is not a fixed point: whatever the union-find makes of it must not be reported as exact --
+            // the frame's tie flag is raised, so the exact flood (mode 0) recomputes it and mode 2 reports it
+            if (threadIdx.x == 0) { *not_converged = 1; exact_flags[b] = 1; }
             return;
         }
         for (int t = 0; t < ntiles; ++t) {
@@ -942,8 +945,10 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
 // but not read: a reachable pixel whose minimum-neighbour mask is 0 is a seed (ws_uf_tile_frame; every other reachable
 // pixel got its level from a neighbour), only seeds carry a label before this pass, and only their four bytes are
 // fetched -- 1 byte of mask per pixel instead of 4 of labels.
+// (F carries no __restrict__: seed and root words are READ while the int4 stores of other lanes rewrite them with the
+// value they already hold -- seeds are the only labelled pixels before this pass and the pass never changes one)
 __global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ minmask,
-                                                            int *__restrict__ F, uint8_t *__restrict__ bad, int *__restrict__ tie_flags,
+                                                            int *F, uint8_t *__restrict__ bad, int *__restrict__ tie_flags,
                                                             int64_t n)
 {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -1137,8 +1142,9 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict_
 __global__ void __launch_bounds__(256) ws_k2_relax_tail_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val,
                                                                 const unsigned *__restrict__ L, unsigned *__restrict__ K2,
                                                                 const uint8_t *__restrict__ active, uint8_t *__restrict__ dirtyA,
-                                                                uint8_t *__restrict__ dirtyB, int *__restrict__ not_converged, int H, int W,
-                                                                int tilesX, int tilesY, int max_rounds)
+                                                                uint8_t *__restrict__ dirtyB, int *__restrict__ not_converged,
+                                                                int *__restrict__ exact_flags, int H, int W, int tilesX, int tilesY,
+                                                                int max_rounds)
 {
     __shared__ WsK2Lds lds;
     ws_for_frames(frame_list, blockIdx.x, gridDim.x, [&](const int b) {
@@ -1151,7 +1157,7 @@ __global__ void __launch_bounds__(256) ws_k2_relax_tail_kernel(const int *__rest
         for (int t = threadIdx.x; t < ntiles; t += 256) any = any || (marks[t] != 0 && act[t] != 0);
         if (!__syncthreads_or(any)) return;
         if (round >= max_rounds) {
-            if (threadIdx.x == 0) *not_converged = 1;
+            if (threadIdx.x == 0) { *not_converged = 1; exact_flags[b] = 1; }  // see ws_relax_tail_kernel
             return;
         }
         for (int t = 0; t < ntiles; ++t) {
@@ -1638,6 +1644,9 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                 lds_attr_set[dev].store(true);
             }
         }
+        // frame flags first: the tail kernels may raise flags2 (a fixed point they had to abandon)
+        PCSEG_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * B, s));
+        PCSEG_CHECK_HIP(hipMemsetAsync(flags2, 0, sizeof(int) * B, s));
         // both mark buffers start empty (round 0 visits every tile regardless)
         PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, ntiles_max, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(dirtyB, 0, ntiles_max, s));
@@ -1652,7 +1661,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                 uint8_t *t = din; din = dout; dout = t;
             }
             PCSEG_LAUNCH(ws_relax_tail_kernel<RT>, dim3(B), dim3(RG::THREADS), RG::LDS_BYTES, s, inputs, val, L, din, dout, changed,
-                         changed + 6, H, W, tilings[0], tilings[1], WS_GRID_ROUNDS, max_rounds);
+                         changed + 6, flags2, H, W, tilings[0], tilings[1], WS_GRID_ROUNDS, max_rounds);
             PCSEG_CHECK_LAUNCH();
         }
         const dim3 ugrid_full((W + UF_TW - 1) / UF_TW, (H + UF_TH - 1) / UF_TH, B);
@@ -1698,8 +1707,6 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             return PCSEG_OK;
         };
         uint8_t *active = dirtyB;  // both mark buffers are empty again after a fixed point: free between the two loops
-        PCSEG_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * B, s));
-        PCSEG_CHECK_HIP(hipMemsetAsync(flags2, 0, sizeof(int) * B, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(active, 0, ntiles_max, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, ntiles_max, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(uf_bad1, 0, n, s));
@@ -1745,7 +1752,8 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                 uint8_t *t = din; din = dout; dout = t;
             }
             PCSEG_LAUNCH(ws_k2_relax_tail_kernel, dim3(B), dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
-                         (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, changed + 6, H, W, tilesX, tilesY, max_rounds);
+                         (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, changed + 6, flags2, H, W, tilesX, tilesY,
+                         max_rounds);
             PCSEG_CHECK_LAUNCH();
             PCSEG_LAUNCH(ws_pack_kernel, lgrid, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)L, (const unsigned *)K2,
                          (const int *)flags, (const uint8_t *)active_tiles, K64, npx, W, tilesX, tilesY);

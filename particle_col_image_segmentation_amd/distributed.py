@@ -67,7 +67,20 @@ def gather_tables(tables, device=None, group=None, presorted=False):
     return out
 
 
-def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, planes=5, check=True, **table_kwargs):
+def _agree_planes(local_planes, group, device):
+    """Plane count of the dataset as every rank must see it: the maximum over the ranks (a rank that owns no frame
+    knows none and contributes 0).  One tiny all-reduce; without it a rank with an empty shard would build its empty
+    tables from a default width and enter the padded all-gather with a different column count than its peers."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(local_planes)
+    if device is None and dist.get_backend(group) == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([int(local_planes)], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
+def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, planes=None, check=True, **table_kwargs):
     """BASELINE configs 3 / 5: frames ``rank, rank + world, ...`` of a dataset go through ``pipe`` in batches of
     ``batch`` and the tables of all ranks are gathered once at the end.  ``make_batch(frame_ids)`` returns the
     ``(len(frame_ids), planes, H, W)`` float32 CUDA stack of those frames (e.g. ``synth.gen_batch_torch`` per seed, or
@@ -79,7 +92,8 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
     device tables are concatenated, all-gathered as device tensors (RCCL when the group is NCCL) and downloaded ONCE;
     the host epilogue (``pipe.host_tables``) then runs on the gathered rows.  A rank that owns no frame
     (``n_frames < world``) contributes ``pipe.empty_device_tables``, so that every rank enters the same collectives with
-    the same column counts.  ``table_kwargs`` (ratios, distances, raster) go to ``host_tables``."""
+    the same column counts.  The plane count comes from the data (the first batch a rank makes; ranks agree on it with one
+    all-reduce), ``planes`` only overrides it.  ``table_kwargs`` (ratios, distances, raster) go to ``host_tables``."""
     rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     mine = shard_frames(n_frames, rank, world)
@@ -87,15 +101,21 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
     parts = []
     pending = collections.deque()
     depth = max(1, int(getattr(pipe, "lanes", 1)))  # batches the pipeline keeps in flight: a table is assembled (which
+    seen_planes = 0
     for i in range(0, len(mine), batch):            # waits for its batch) only once that many newer batches are queued
         ids = mine[i:i + batch]
-        pending.append((pipe.run(make_batch(ids)), ids))
+        frames = make_batch(ids)
+        if not seen_planes and hasattr(frames, "shape") and len(frames.shape) == 4:
+            seen_planes = int(frames.shape[1])
+        pending.append((pipe.run(frames), ids))
         if len(pending) > depth:
             res, rid = pending.popleft()
             parts.append(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
     while pending:
         res, rid = pending.popleft()
         parts.append(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
+    if planes is None:
+        planes = _agree_planes(seen_planes, group, device) or 5
     if parts:
         merged = {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
     else:

@@ -17,8 +17,13 @@ def _run_and_compare(stack, ct):
     res.synchronize()
     assert int(res["overflow"].sum()) == 0 and int(res["ws_overflow"].sum()) == 0
     refs, wall, procs = parity.run_oracle(stack.cpu().numpy(), ct)
-    n = parity.compare(res, range(stack.shape[0]), refs, sums_rtol=1e-6)
+    n = parity.compare(res, range(stack.shape[0]), refs, sums_rtol=1e-6)  # images, counts, classification, merged groups
     assert n == stack.shape[0]
+    # the device-assembled tables of the same batch: `groups` rows, cells.group / cells.group_combined
+    ids = [1000 + 3 * i for i in range(stack.shape[0])]
+    tabs = pipe.tables(res, frame_ids=ids, check=False)
+    good = sum(1 for r in refs if not r["nan"])
+    assert parity.compare_tables(tabs, ids, refs) == good
     return res, refs
 
 

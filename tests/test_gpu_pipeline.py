@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
+from oracle import parity
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -105,6 +106,12 @@ def test_pipeline_matches_oracle(H, W, ties):
             assert fr[cols.index(name + "_count")] == cnt[name]
             assert fr[cols.index(name + "_density")] == dens[name]
             assert fr[cols.index(name + "_area_ratio")] == ratio[name]
+    # the same frames through the helper the large-shape tests and bench.py use (images, classification, merged groups),
+    # and the DEVICE-ASSEMBLED tables: `groups` rows and the group / group_combined columns of `cells`
+    # (tiff_analysis.py:843-878) against the oracle's merged_clusters
+    prefs = [parity.describe(ref, ct) for ref in refs]
+    assert parity.compare(res, range(len(refs)), prefs, sums_rtol=1e-9) == len(refs)
+    assert parity.compare_tables(tabs, seeds, prefs) == len(refs)
     # ROI table: ratios within 1e-6 relative of the oracle's
     rois = tabs["rois"]
     for b, ref in enumerate(refs):

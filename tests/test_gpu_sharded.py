@@ -8,6 +8,7 @@ import pytest
 
 from conftest import GOLDEN
 from oracle import oracle as orc
+from oracle import parity
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -45,10 +46,12 @@ def test_run_sharded_real_pipeline_matches_per_frame_oracle():
         np.testing.assert_allclose(rows[:, 10:12], exp[:, 7:9], rtol=1e-6)
         assert fr[i, 2] == m
         try:
-            ref = orc.segment_frame(frames[i], ct, merged=False)
+            ref = orc.segment_frame(frames[i], ct, merged=True)
         except ValueError:
             n_nan += 1
             continue
+        # merged groups as the gathered tables hold them (`groups` rows, cells.group / cells.group_combined)
+        assert parity.compare_tables(tabs, [i], [parity.describe(ref, ct)]) == 1
         crow = cells[cells[:, 0] == i]
         exp_regs = []
         for s, name in enumerate(names):
@@ -82,3 +85,20 @@ def test_sharded_fixture_is_what_the_pipeline_produces():
             np.testing.assert_allclose(fresh[k], stored[k], rtol=1e-12, atol=0)
         else:
             np.testing.assert_array_equal(fresh[k], stored[k])
+    # ... and the rows themselves are the ORACLE's (not only what this code happens to produce): merged groups, the group
+    # columns of `cells`, the classification and the cluster cell counts of every frame the reference does not raise on
+    from particle_col_image_segmentation_amd import synth
+    ct = dict(synth.CELL_TYPES_5)
+    checked = 0
+    for i in range(mod.N_FRAMES):
+        st = synth.gen_frame(mod.SEED0 + i, mod.H, mod.W, ties=(i % 4 == 3))
+        try:
+            ref = orc.segment_frame(st, ct, merged=True)
+        except ValueError:
+            continue
+        checked += parity.compare_tables(fresh, [i], [parity.describe(ref, ct)])
+        crow = fresh["cells"][fresh["cells"][:, 0] == i]
+        exp = sorted([(r.label, 1, r.area, 1) for rs in ref["cell_pos"].values() for r in rs] +
+                     [(r.label, 2, r.area, r.cells) for rs in ref["cell_clusters"].values() for r in rs])
+        assert [(int(r[1]), int(r[3]), int(r[4]), int(r[11])) for r in crow] == exp
+    assert checked >= mod.N_FRAMES // 2

@@ -25,6 +25,21 @@ def test_run_oracle_matches_direct_call():
         assert ref["recreated"] == parity._digest(direct["recreated"], np.uint8)
         assert ref["n_labels"] == int(direct["label_im"].max())
         np.testing.assert_array_equal(ref["roi_sums"], direct["roi_sums"])
+        # classification vectors and merged groups describe the same result
+        names = parity.slot_names(ct)
+        n = ref["n_labels"]
+        assert ref["classes"]["kind"].shape == (n,)
+        for s_, name in enumerate(names):
+            cells = [r.label for r in direct["cell_pos"].get(name, [])]
+            clus = direct["cell_clusters"].get(name, [])
+            k = ref["classes"]["kind"]
+            assert list(np.nonzero((k == 1) & (ref["classes"]["slot_of"] == s_))[0] + 1) == cells
+            assert [int(ref["classes"]["cells"][r.label - 1]) for r in clus] == [r.cells for r in clus]
+        for key, groups in direct["merged_clusters"].items():
+            g = ref["groups"][4 if key == "combined" else names.index(key)]
+            assert list(g["area"]) == [e["area"] for e in groups]
+            assert list(g["members"]) == [r.label for e in groups for r in e["regions"]]
+            assert list(np.diff(g["offsets"])) == [len(e["regions"]) for e in groups]
         # a digest is sensitive to a single changed pixel
         changed = direct["label_im"].copy()
         changed[0, 0] += 1
