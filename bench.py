@@ -11,9 +11,11 @@ over one batch of 64 frames of 1024x1024x5 float32 that is already resident in H
 independent, so N ranks each process their own batch (weak scaling, no data-path collective); the only exchange is
 the RCCL all-gather of the ROI table, done once after the timed region.
 
-The JSON line carries `roofline` (dominant kernel, HIP events recorded on the launch stream inside the timed
-region) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample; reported, not the
-target).
+The timed region carries no instrumentation: by default every step is ONE hipGraph replay (FramePipeline(graph=True),
+two graphs in flight).  The JSON line carries `roofline` (dominant kernel; HIP events on the launch streams in an
+instrumented pass of the same chain, same number of batches in flight, right after the timed region -- a graph replay
+cannot be bracketed kernel by kernel -- plus the same kernel with nothing beside it, `alone`) and `cpu_baseline` (the CPU
+oracle timed on this box's host cores on a bounded sample; reported, not the target).
 """
 import argparse
 import ctypes
@@ -29,15 +31,12 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s 
 CHAIN_BYTES_PER_PIXEL = 28  # 5 x f32 in + int32 class-CC mask + int32 ROI mask
 
 # algorithmic (compulsory) bytes per pixel of one launch of each kernel, stated in DESIGN.md
+# (kernels of the default chain that can come out on top of the per-kernel table)
 KERNEL_BYTES_PER_PIXEL = {
-    "argmax_kernel": 21.0, "median5_kernel": 2.0, "ccl_tile_kernel": 5.0, "ccl_border_kernel": 0.0,
-    "ccl_flatten_count_kernel": 8.0, "ccl_relabel_kernel": 8.0, "ccl_flatten_kernel": 8.0,
-    "region_reduce_kernel": 24.0, "region_reduce_col_kernel": 24.0, "edt_bits_kernel": 1.0, "edt_bits4_kernel": 1.0,
-    "edt_row_kernel": 4.0, "edt_reach_kernel": 2.0,
-    "ws_init_kernel": 21.0, "ws_relax_kernel": 12.0, "ws_k2_relax_kernel": 12.0, "ws_uf_tile_kernel": 13.0,
-    "ws_uf_border_kernel": 0.0, "ws_uf_label_kernel": 12.0, "ws_uf_label4_kernel": 12.0, "ws_check_kernel": 8.0,
-    "ws_exact_kernel": 21.0, "locmax_candidates_kernel": 9.0, "locmax_propagate_kernel": 5.0,
-    "bitrun_link_kernel": 0.125, "dilate_bits_kernel": 0.25, "set_bits4_kernel": 1.125,
+    "classmap_median_ccl_kernel": 26.0, "ccl_flatten_count_kernel": 4.0, "ccl_relabel_kernel": 8.0,
+    "region_reduce_col_kernel": 24.0, "edt_bits_kernel": 5.125, "edt_row_kernel": 4.0, "edt_reach_kernel": 2.0,
+    "locmax_candidates_kernel": 13.0, "locmax_propagate_kernel": 5.0,
+    "ws_relax_kernel": 12.0, "ws_uf_tile_kernel": 13.0, "ws_uf_label4_kernel": 9.0, "ws_exact_kernel": 21.0,
 }
 
 
@@ -51,8 +50,12 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = 2 per core)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event table to stderr")
-    ap.add_argument("--lanes", type=int, default=8,
-                    help="host threads (each with its own stream pair) that consecutive batches alternate between")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="batches in flight (0 = the pipeline's default: 2 graph replays, or 8 host threads with --eager)")
+    ap.add_argument("--eager", action="store_true",
+                    help="A/B aid: launch every kernel from host threads (round 2's mode) instead of replaying hipGraphs")
+    ap.add_argument("--batch64-frames", type=int, default=64,
+                    help="frames of the `batch64` leg (0 = off): the quantised boundary plane at BASELINE config 2's own batch size")
     ap.add_argument("--single-class-stream", action="store_true",
                     help="A/B aid: merges and particle fill on the class-map stream instead of streams of their own")
     ap.add_argument("--serial", action="store_true",
@@ -69,7 +72,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(res, stack, cell_types, n_frames):
+def cpu_baseline(res, stack, cell_types, n_frames, tables=None):
     """CPU oracle (bit-exact restatement of the reference chain, 'port') on this box's host cores, one frame per
     process, on the FIRST n frames of the batch that was just timed -- and, because the oracle's results for those
     frames exist anyway, the parity check of the benchmark itself: the GPU's masks for exactly these frames must be
@@ -79,7 +82,11 @@ def cpu_baseline(res, stack, cell_types, n_frames):
     n = min(int(stack.shape[0]), n_frames or 2 * cores)
     H, W = int(stack.shape[2]), int(stack.shape[3])
     refs, wall, procs = parity.run_oracle(stack[:n].cpu().numpy(), cell_types, merged=True, processes=cores)
-    checked = parity.compare(res, range(n), refs, sums_rtol=1e-6)
+    checked = parity.compare(res, range(n), refs, sums_rtol=1e-6)  # images, counts, classification, merged groups, ROI sums
+    if tables is not None:
+        # ... and the device-assembled `groups` table / group columns of `cells` of the same frames
+        host = {k: tables[k].cpu().numpy() for k in ("groups", "cells")}
+        parity.compare_tables(host, list(range(n)), refs)  # (rank 0 numbers its frames 0 .. B-1)
     per = [r["seconds"] for r in refs]
     block = {"value": round(n * H * W / wall / 1e6, 4), "unit": "Mpixels/s", "cores": procs, "kind": "port",
              "sample": "the first %d frames (%dx%dx5) of the timed batch, full chain incl. O(R) merge, %d processes, "
@@ -131,21 +138,27 @@ def end_to_end_leg(args, stack, cell_types, pipe, dev, world, kernel_only_mpx):
              "fraction_of_kernel_only": round(e2e / kernel_only_mpx, 3), "gathered_roi_rows": int(tabs["rois"].shape[0])}
     if world == 1:
         host = [stack.cpu().pin_memory() for _ in range(2)]
+        dbuf = [torch.empty_like(stack) for _ in range(2)]  # two device buffers, refilled in turn (graph mode keys on them)
         up = FrameUploader((C, H, W), batch=B, device=dev)
-        for k in range(2):  # warm: the uploader's device buffers, both staging slots
-            d, ev = up.upload_staged(host[k])
-            ev.synchronize()
-            pipe.run(d).synchronize()
+        events, results = [None, None], [None, None]
+
+        def feed(k):
+            j = k % 2
+            if results[j] is not None:  # the kernels that still read device buffer j: the copy waits for them on the GPU
+                for ev in results[j].done_events():
+                    up.copy_stream.wait_event(ev)
+            if events[j] is not None:
+                events[j].synchronize()  # staging buffer j is free again
+            d, events[j] = up.upload_staged(host[j], out=dbuf[j])
+            results[j] = pipe.run(d)
+
+        for k in range(max(2, pipe.lanes)):  # warm: both staging slots, both device buffers, the graphs keyed on them
+            feed(k)
         pipe.synchronize()
         up.bytes_uploaded = 0
         t0 = time.perf_counter()
-        events, res = [None, None], None
         for k in range(n_batches):
-            if events[k % 2] is not None:
-                events[k % 2].synchronize()
-            d, events[k % 2] = up.upload_staged(host[k % 2])
-            res = pipe.run(d)
-        res.synchronize()
+            feed(k)
         pipe.synchronize()
         dt = time.perf_counter() - t0
         block["pcie_inclusive"] = {"value": round(n_batches * B * H * W / dt / 1e6, 1), "unit": "Mpixels/s",
@@ -219,6 +232,54 @@ def main():
         print(line, flush=True)
 
 
+def _timing_pass(lib, fn, sync):
+    """Run ``fn`` with the library's per-launch HIP events on: returns ({kernel: (launches, total ms)},
+    relaxation tiles processed, relaxation launches)."""
+    lib.pcseg_watershed_counters(None, 1)
+    lib.pcseg_timing_enable(1)
+    fn()
+    sync()
+    nbytes = lib.pcseg_timing_report(None, 0)
+    buf = ctypes.create_string_buffer(nbytes + 16)
+    lib.pcseg_timing_report(buf, nbytes + 16)
+    lib.pcseg_timing_enable(0)
+    tiles = (ctypes.c_int64 * 4)()
+    lib.pcseg_watershed_counters(tiles, 0)
+    kernels = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.split("\t")
+        kernels[name] = (int(calls), float(ms))
+    return kernels, int(tiles[0]), int(tiles[1])
+
+
+def batch64_leg(args, stack, cell_types):
+    """The quantised boundary plane (k/100 vote fractions) at BASELINE config 2's OWN batch size: every frame floods
+    through equal-valued seeds, i.e. through the exact emulation of the reference's heap, one wave per frame -- the
+    latency-bound operating point (the `secondary` leg is the throughput-bound one).  Bit-exact check of two frames."""
+    import torch
+    from oracle import parity
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline
+    n = min(int(args.batch64_frames), int(stack.shape[0]))
+    q = stack[:n].clone()
+    q[:, 3] = torch.round(q[:, 3] * 100) / 100
+    H, W = int(q.shape[2]), int(q.shape[3])
+    solo = FramePipeline(cell_types, lanes=1)
+    solo.run(stack[:n]).synchronize()  # allocator priming on the tie-free frames (same sizes, milliseconds)
+    solo.synchronize()
+    t0 = time.perf_counter()
+    res = solo.run(q)
+    res.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    check = [0, n - 1] if n > 1 else [0]
+    refs, _, _ = parity.run_oracle(q[check].cpu().numpy(), cell_types, merged=True, processes=2)
+    checked = parity.compare(res, check, refs, sums_rtol=1e-6)
+    return {"workload": "boundary plane quantised to k/100: ONE batch of %d frames %dx%dx5, full kernel chain, inputs resident "
+                        "in HBM (BASELINE config 2's shape on random-forest-like input)" % (n, H, W),
+            "value": round(n * H * W / dt / 1e6, 3), "unit": "Mpixels/s", "steps": 1, "ms_per_step": round(1e3 * dt, 1),
+            "frames": n, "tie_fallback_frames": int(res["tie_flags"].sum().item()), "parity_checked_frames": checked}
+
+
 def _run(args):
     import torch
     import torch.distributed as dist
@@ -241,24 +302,27 @@ def _run(args):
 
     B, H, W = args.batch, args.size, args.size
     lib = _lib.load()
+    ct = dict(synth.CELL_TYPES_5)
     stack = synth.gen_batch_torch(10_000 + rank * B, B, H, W, dev)
     if args.levels > 0:
         stack[:, 3] = torch.round(stack[:, 3] * args.levels) / args.levels
-    pipe = FramePipeline(dict(synth.CELL_TYPES_5), overlap=not args.serial, lanes=args.lanes,
-                         multi_stream=not args.single_class_stream)
+    graph = not args.eager
+    pipe = FramePipeline(ct, overlap=not args.serial, lanes=args.lanes or None, multi_stream=not args.single_class_stream,
+                         graph=graph)
     res = None
-    # setup (not warmup): two priming passes so that torch's caching allocator holds every workspace block before the
-    # W untimed warmup steps and the K timed steps
-    for _ in range(2 + args.warmup):
+    # setup (not warmup): in graph mode the first pass through each lane captures its graph (one plain run + the capture);
+    # in eager mode two priming passes fill torch's caching allocator with every workspace block.  Then W untimed warmup
+    # steps and the K timed steps.
+    for _ in range(max(2, pipe.lanes) + args.warmup):
         res = pipe.run(stack)
-    pipe.synchronize()  # run() only hands the batch to a lane: drain the lanes, then torch.cuda.synchronize()
+    pipe.synchronize()
 
     def barrier():
         if use_dist:
             dist.barrier()
 
-    lib.pcseg_timing_enable(1)
-    lib.pcseg_watershed_counters(None, 1)
+    # ---- the timed region: K steps, nothing but the chain (no event records, no counters read)
+    lib.pcseg_timing_enable(0)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -267,36 +331,31 @@ def _run(args):
     pipe.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    nbytes = lib.pcseg_timing_report(None, 0)
-    buf = ctypes.create_string_buffer(nbytes + 16)
-    lib.pcseg_timing_report(buf, nbytes + 16)
-    lib.pcseg_timing_enable(0)
-    timed_tiles = (ctypes.c_int64 * 4)()
-    lib.pcseg_watershed_counters(timed_tiles, 0)
-    # The same kernels once more with nothing beside them (2 steps, one stream, outside the timed region): in the timed
-    # region up to four streams share the CUs, so a launch's duration there says how the GPU was shared, not how good
-    # the kernel is.  Reported next to the timed-region figure as roofline.alone.
-    alone = None
-    if rank == 0 and not args.serial:
-        solo = FramePipeline(dict(synth.CELL_TYPES_5), overlap=False)
-        solo.run(stack)
-        torch.cuda.synchronize()
-        lib.pcseg_timing_enable(1)
-        lib.pcseg_watershed_counters(None, 1)
-        for _ in range(2):
-            solo.run(stack)
-        torch.cuda.synchronize()
-        n2 = lib.pcseg_timing_report(None, 0)
-        buf2 = ctypes.create_string_buffer(n2 + 16)
-        lib.pcseg_timing_report(buf2, n2 + 16)
-        lib.pcseg_timing_enable(0)
-        solo_tiles = (ctypes.c_int64 * 4)()
-        lib.pcseg_watershed_counters(solo_tiles, 0)
-        alone = (buf2.value.decode(), solo_tiles[0], solo_tiles[1], 2)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- per-kernel durations (rank 0): HIP events on the launch streams.  (a) the chain as the timed region runs it --
+    # same streams, same number of batches in flight -- launched eagerly, because the kernels of a graph replay cannot be
+    # bracketed one by one; (b) the same kernels with nothing beside them (one stream): a launch's duration under (a) says
+    # how the CUs were shared, under (b) how good the kernel is.
+    insitu = alone = None
+    if rank == 0:
+        steps_i = max(2, min(args.steps, 8))
+        probe = FramePipeline(ct, overlap=not args.serial, lanes=pipe.lanes, multi_stream=not args.single_class_stream)
+        for _ in range(pipe.lanes + 1):
+            probe.run(stack)
+        probe.synchronize()
+        insitu = _timing_pass(lib, lambda: [probe.run(stack) for _ in range(steps_i)], probe.synchronize) + (steps_i,)
+        if not args.serial:
+            solo = FramePipeline(ct, overlap=False)
+            solo.run(stack)
+            torch.cuda.synchronize()
+            alone = _timing_pass(lib, lambda: [solo.run(stack) for _ in range(2)], torch.cuda.synchronize) + (2,)
+            del solo
+        del probe
+
     # a table overflow would invalidate the measurement; frames on which the reference itself raises (clusters of a type
     # without a single cell -> int(NaN), tiff_analysis.py:776-781) are only counted: they cost the same work
     if int(res["overflow"].sum().item()) or int(res["ws_overflow"].sum().item()):
@@ -317,46 +376,50 @@ def _run(args):
     gather_ms = 1e3 * (time.perf_counter() - t_gat)
     n_rois = int(gathered.shape[0])
 
+    # parity evidence of THIS run, before anything replays the pipeline's graphs again (a replay overwrites `res`):
+    # world == 1: the CPU baseline's frames double as the check (32 by default); world > 1: no CPU baseline (rank 0 at
+    # N = 1 only, by contract), but rank 0 still checks two frames of its timed batch against the oracle
+    cpu_block, checked = None, None
+    if rank == 0 and not args.no_cpu_baseline:
+        if world == 1:
+            cpu_block, checked = cpu_baseline(res, stack, ct, args.cpu_frames, tables)
+        else:
+            from oracle import parity
+            refs, _, _ = parity.run_oracle(stack[[0, B - 1]].cpu().numpy(), ct, merged=True, processes=2)
+            checked = parity.compare(res, [0, B - 1], refs, sums_rtol=1e-6)
     e2e_block = None
     if not args.serial and not args.no_end_to_end:
-        e2e_block = end_to_end_leg(args, stack, dict(synth.CELL_TYPES_5), pipe, dev, world,
-                                   world * B * H * W * args.steps / elapsed / 1e6)
+        e2e_block = end_to_end_leg(args, stack, ct, pipe, dev, world, world * B * H * W * args.steps / elapsed / 1e6)
     if rank == 0:
-        kernels = {}
-        for line in buf.value.decode().splitlines():
-            name, calls, ms = line.split("\t")
-            kernels[name] = (int(calls), float(ms))
+        kernels, tiles_i, launches_i, steps_i = insitu
         if args.kernel_table:
             for name, (calls, ms) in sorted(kernels.items(), key=lambda kv: -kv[1][1]):
                 print("%10.3f ms %7d launches %9.2f us/launch  %s" % (ms, calls, 1e3 * ms / calls, name), file=sys.stderr)
-        dom = max(kernels.items(), key=lambda kv: kv[1][1])
-        dom_name, (dom_calls, dom_ms) = dom
+        dom_name, (dom_calls, dom_ms) = max(kernels.items(), key=lambda kv: kv[1][1])
         short = dom_name.split("<")[0].split(" ")[0].strip("()")
         bpp = KERNEL_BYTES_PER_PIXEL.get(short, 0.0)
-        avg_s = dom_ms / dom_calls / 1e3
-        units = float(B * H * W)  # pixels one launch processes
-        def relax_bytes(tiles, launches, steps):
-            # the relaxation only touches marked tiles: count the 64x64 tiles it really processed; one launch per step is
-            # the set-up round, which reads the three inputs (9 B/px) and writes value keys, seed labels and levels
-            # (12 B/px) for every pixel instead of the 12 B/px of a plain round
-            return 12.0 * 4096.0 * tiles / launches + 9.0 * B * H * W * steps / launches
 
-        launch_bytes = bpp * units
-        if short == "ws_relax_kernel" and timed_tiles[1]:
-            units = 4096.0 * timed_tiles[0] / timed_tiles[1]
-            launch_bytes = relax_bytes(timed_tiles[0], dom_calls, args.steps)
-        achieved = launch_bytes / avg_s / 1e9
+        def launch_block(kern, tiles, launches, steps):
+            calls, ms = kern[dom_name]
+            avg_s = ms / calls / 1e3
+            units = float(B * H * W)  # pixels one launch processes
+            nbytes = bpp * units
+            if short == "ws_relax_kernel" and launches:
+                # the relaxation only touches marked tiles: count the 64x64 tiles it really processed; one launch per step
+                # is the set-up round, which reads the three inputs (9 B/px) and writes value keys, seed labels and levels
+                # (12 B/px) for every pixel instead of the 12 B/px of a plain round
+                units = 4096.0 * tiles / launches
+                nbytes = 12.0 * 4096.0 * tiles / launches + 9.0 * B * H * W * steps / launches
+            return {"launches_per_step": calls / steps, "avg_launch_us": round(1e6 * avg_s, 2),
+                    "algorithmic_bytes_per_launch": round(nbytes), "pixels_per_launch": round(units),
+                    "achieved": round(nbytes / avg_s / 1e9, 2), "frac": round(nbytes / avg_s / 1e9 / HBM_PEAK_GBS, 5)}
+
+        main_block = launch_block(kernels, tiles_i, launches_i, steps_i)
         alone_block = None
-        if alone is not None:
-            text, tiles, launches, steps2 = alone
-            for line in text.splitlines():
-                name, calls, ms = line.split("\t")
-                if name == dom_name:
-                    a_avg = float(ms) / int(calls) / 1e3
-                    a_bytes = relax_bytes(tiles, int(calls), steps2) if short == "ws_relax_kernel" else bpp * B * H * W
-                    alone_block = {"avg_launch_us": round(1e6 * a_avg, 2), "algorithmic_bytes_per_launch": round(a_bytes),
-                                   "achieved": round(a_bytes / a_avg / 1e9, 2), "frac": round(a_bytes / a_avg / 1e9 / HBM_PEAK_GBS, 5),
-                                   "how": "2 extra steps on one stream right after the timed region"}
+        if alone is not None and dom_name in alone[0]:
+            alone_block = launch_block(alone[0], alone[1], alone[2], alone[3])
+            alone_block["how"] = "2 extra steps on one stream after the timed region"
+            alone_block["serial_kernel_ms_per_step"] = round(sum(ms for _, ms in alone[0].values()) / alone[3], 3)
         total_kernel_ms = sum(ms for _, ms in kernels.values())
         value = world * B * H * W * args.steps / elapsed / 1e6
         traffic = None
@@ -372,26 +435,31 @@ def _run(args):
                                    + ": batch of %d frames %dx%dx5 float32 per GPU, full kernel chain, "
                                    "inputs resident in HBM" % (B, H, W),
                        "frames_per_gpu": B, "height": H, "width": W, "planes": 5, "parallelism": "frames x%d" % world,
+                       "launch": ("one hipGraph replay per step, %d in flight" if graph else "eager launches from %d host threads") % pipe.lanes,
                        "tie_fallback_frames_last_step": tie_frames, "reference_nan_frames_rank0": nan_frames,
                        "gathered_roi_rows": n_rois, "table_assembly_ms_last_batch": round(table_ms, 3),
                        "roi_table_all_gather_ms": round(gather_ms, 3)},
-            "roofline": {"bound": "hbm", "kernel": short, "launches_per_step": dom_calls / args.steps,
-                         "avg_launch_us": round(1e6 * avg_s, 2), "algorithmic_bytes_per_pixel": bpp,
-                         "algorithmic_bytes_per_launch": round(launch_bytes),
-                         "pixels_per_launch": round(units),
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "alone": alone_block,
-                         "share_of_kernel_time": round(dom_ms / total_kernel_ms, 4),
-                         "chain_bytes_per_pixel": CHAIN_BYTES_PER_PIXEL,
-                         "chain_achieved_GBps": round(CHAIN_BYTES_PER_PIXEL * value / world / 1e3, 3),
-                         "chain_frac": round(CHAIN_BYTES_PER_PIXEL * value / world / 1e3 / HBM_PEAK_GBS, 6)},
+            "roofline": dict({"bound": "hbm", "kernel": short, "algorithmic_bytes_per_pixel": bpp}, **main_block,
+                             **{"peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,
+                                "how": "HIP events on the launch streams, %d steps of the same chain with %d batches in flight, launched "
+                                       "eagerly right after the timed region (a graph replay cannot be bracketed per kernel)"
+                                       % (steps_i, pipe.lanes),
+                                "alone": alone_block,
+                                "share_of_kernel_time": round(dom_ms / total_kernel_ms, 4),
+                                "chain_bytes_per_pixel": CHAIN_BYTES_PER_PIXEL,
+                                "chain_achieved_GBps": round(CHAIN_BYTES_PER_PIXEL * value / world / 1e3, 3),
+                                "chain_frac": round(CHAIN_BYTES_PER_PIXEL * value / world / 1e3 / HBM_PEAK_GBS, 6)}),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], checked = cpu_baseline(res, stack, dict(synth.CELL_TYPES_5), args.cpu_frames)
+        if cpu_block is not None:
+            out["cpu_baseline"] = cpu_block
+        if checked is not None:
             out["config"]["parity_checked_frames"] = checked
         out["end_to_end"] = e2e_block
-        if world == 1 and args.secondary_batch > 0 and not args.levels and not args.serial:
-            out["secondary"] = secondary_leg(args, stack, dict(synth.CELL_TYPES_5), pipe)
+        if world == 1 and not args.levels and not args.serial:
+            if args.batch64_frames > 0:
+                out["batch64"] = batch64_leg(args, stack, ct)
+            if args.secondary_batch > 0:
+                out["secondary"] = secondary_leg(args, stack, ct, pipe)
         line = json.dumps(out)
     else:
         line = None

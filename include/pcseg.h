@@ -222,6 +222,17 @@ int pcseg_merge_groups_runs(const uint32_t *dilated_bits, const int32_t *run_par
                             int B, int H, int W, int cap, int list_cap, void *workspace, size_t workspace_bytes,
                             pcseg_stream_t stream);
 
+/* get_merged_regions' grouping AND the member sums of its groups (tiff_analysis.py:843-878) in ONE launch, on the
+ * run-based components of pcseg_dilate_ccl_runs_u8: what pcseg_merge_groups_runs followed by pcseg_group_reduce
+ * computes, with the list of type slot `slot` read in place from the (B, n_slots, cap) region lists and (B, n_slots)
+ * list lengths pcseg_classify_regions writes (list capacity = cap).  group_of int32 (B, cap): every entry below the
+ * list length is written; n_groups int32[B]; group_stats int64 (B, cap, 8): rows below n_groups[b] are written.
+ * Workspace: pcseg_merge_groups_workspace_bytes(B, cap) (only touched by frames that list more than 4096 regions). */
+int pcseg_merge_groups_fused(const uint32_t *dilated_bits, const int32_t *run_parent, const int64_t *stats,
+                             const int32_t *region_lists, const int32_t *n_lists, int slot, int n_slots,
+                             int32_t *group_of, int32_t *n_groups, int64_t *group_stats, int B, int H, int W, int cap,
+                             void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
 /* member sums of the groups: group_stats int64 (B, list_cap, 8) = area, sum_row,
  * sum_col, min_row, min_col, max_row+1, max_col+1, members (tiff_analysis.py:855-872) */
 int pcseg_group_reduce(const int64_t *stats, const int32_t *region_list, const int32_t *n_list,
@@ -290,6 +301,15 @@ int pcseg_table_layout(const pcseg_table_inputs *in, int64_t *totals, void *work
                        pcseg_stream_t stream);
 int pcseg_table_write(const pcseg_table_inputs *in, double *rois, double *cells, double *groups, int64_t *frames,
                       void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
+/* ---- C14 for a batch (HCN_nanosims_rois_activity_distance_5iso_YG.m:260-268): dist[i] = distance from row i of the dense
+ * `cells` table pcseg_table_write has just filled to the nearest row of the OTHER of the two cell types (slots 0 and 1 of
+ * class_slot, a HOST array class value -> slot) in the same frame, / (size / raster) (the script: size 512, raster 19);
+ * positions (centroid_col + 1, centroid_row + 1) as MATLAB's regionprops reports them; NaN for rows without an entry
+ * (another type, or a frame in which one of the two types is absent).  `workspace` is the one pcseg_table_layout /
+ * pcseg_table_write used (it holds the frames' row offsets).  PARITY UNPINNED (no MATLAB here). */
+int pcseg_cell_distances(const double *cells, int64_t n_rows, int ncol, const uint8_t *class_slot, double raster, double size,
+                         double *dist, int B, const void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
 
 /* ---- X1 (north_star extension; refine_boundaries.py:22 imports skimage.filters and never calls it): the library
  * SURVEY.md 8a names is the oracle -- skimage.filters.threshold_otsu(float32 image, nbins=256), pinned by

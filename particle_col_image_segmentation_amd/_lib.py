@@ -57,6 +57,7 @@ SIGNATURES = {
     "pcseg_dilate_ccl_runs_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_dilate_ccl_runs_u8": (c_int, [_P, c_uint64, _I, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_merge_groups_runs": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, c_size_t, _P]),
+    "pcseg_merge_groups_fused": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_group_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "pcseg_classify_regions": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "pcseg_nearest_dist_f64": (c_int, [_P, _I, _P, _I, _P, _P]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "pcseg_table_workspace_bytes": (c_size_t, [_I, _I]),
     "pcseg_table_layout": (c_int, [_P, _P, _P, c_size_t, _P]),
     "pcseg_table_write": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "pcseg_cell_distances": (c_int, [_P, c_int64, _I, _P, c_double, c_double, _P, _I, _P, c_size_t, _P]),
     "pcseg_otsu_hist_f32": (c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "pcseg_otsu_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "pcseg_morph3x3": (c_int, [_P, _P, _I, _I, _I, _I, _P]),

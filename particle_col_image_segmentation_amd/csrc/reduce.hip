@@ -497,6 +497,137 @@ __global__ void __launch_bounds__(256) merge_groups_kernel(const int *__restrict
     if (threadIdx.x == 0) n_groups[b] = carry;
 }
 
+// ---- A6 tail in ONE launch per merge (tiff_analysis.py:843-878): centroid keys, grouping in order of the first member
+// and the member sums of every group.  One 1024-thread block per frame: a frame lists a few hundred regions, so every
+// entry has a thread of its own and the union-find chain walks of the key look-ups (pure latency) all run at once; the
+// hash table of the grouping lives in LDS (the three separate kernels kept it in global memory, where every probe of
+// a block's dependent chain was a memory round trip: 117 us per launch against a handful).  Lists longer than MG_LDS
+// entries fall back to the caller's global scratch, same code.  region_list / n_list are addressed in place inside the
+// (B, n_slots, cap) / (B, n_slots) arrays of pcseg_classify_regions (no per-slot copies).
+constexpr int MG_THREADS = 1024, MG_LDS = 4096;
+
+__device__ __forceinline__ int block_exclusive_scan1024(int v, int *total, int *wsum)
+{
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    int inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < MG_THREADS / 64; ++w) {
+        if (w < wid) base += wsum[w];
+        tot += wsum[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ void __launch_bounds__(MG_THREADS) merge_fused_kernel(const unsigned *__restrict__ run_bits, const int *__restrict__ run_parent,
+                                                                 const long long *__restrict__ stats, const int *__restrict__ region_list,
+                                                                 const int *__restrict__ n_list, int slot, int n_slots,
+                                                                 int *__restrict__ group_of, int *__restrict__ n_groups,
+                                                                 long long *__restrict__ gstats, int *__restrict__ key_ws,
+                                                                 int *__restrict__ first_ws, int *__restrict__ gid_ws, int H, int W, int cap,
+                                                                 int list_cap)
+{
+    __shared__ int s_key[MG_LDS], s_first[MG_LDS + 1], s_gid[MG_LDS];
+    __shared__ int wsum[MG_THREADS / 64];
+    const int b = blockIdx.x;
+    const int R = min(n_list[b * n_slots + slot], list_cap);
+    const int *lst = region_list + ((int64_t)b * n_slots + slot) * cap;
+    const bool in_lds = R <= MG_LDS;  // block-uniform
+    int *key = in_lds ? s_key : key_ws + (int64_t)b * list_cap;
+    int *first = in_lds ? s_first : first_ws + (int64_t)b * (list_cap + 1);
+    int *gid = in_lds ? s_gid : gid_ws + (int64_t)b * list_cap;
+    int *gof = group_of + (int64_t)b * list_cap;
+    long long *gs = gstats + (int64_t)b * list_cap * 8;
+    const int64_t n = (int64_t)H * W;
+    const int *par = run_parent + (int64_t)b * n;
+    const long long *st = stats + (int64_t)b * cap * 8;
+    const int nch = (H + 31) / 32;
+    // (1) keys: the run component under the truncated centroid (0: centroid on a clear pixel -> dropped, :848)
+    for (int k = threadIdx.x; k < R; k += MG_THREADS) {
+        int key_k = 0;
+        const int r = lst[k];
+        if (r >= 0 && r < cap) {
+            const long long a = st[(int64_t)r * 8 + 0];
+            if (a > 0) {
+                const long long y = st[(int64_t)r * 8 + 1] / a, x = st[(int64_t)r * 8 + 2] / a;
+                if (y >= 0 && y < H && x >= 0 && x < W) {
+                    const unsigned word = run_bits[((int64_t)b * nch + (int)(y >> 5)) * W + x];
+                    const int j = (int)(y & 31);
+                    if ((word >> j) & 1u) {
+                        const unsigned below = ~word & ((1u << j) - 1u);
+                        const int start = below ? 32 - __clz(below) : 0;
+                        key_k = (int)((y - j + start) * W + x);
+                        int q;
+                        while ((q = par[key_k]) != key_k) key_k = q;
+                        key_k += 1;
+                    }
+                }
+            }
+        }
+        key[k] = key_k;
+        gid[k] = 0;
+    }
+    for (int k = threadIdx.x; k <= R; k += MG_THREADS) first[k] = 0x7FFFFFFF;
+    __syncthreads();
+    // (2) slot table (open addressing over R slots): gid[slot] = key owning the slot, first[slot] = smallest list position
+    for (int k = threadIdx.x; k < R; k += MG_THREADS) {
+        const int kk = key[k];
+        if (kk <= 0) continue;
+        unsigned slot_i = ((unsigned)kk * 2654435761u) % (unsigned)R;
+        for (;;) {
+            const int owner = atomicCAS(&gid[slot_i], 0, kk);
+            if (owner == 0 || owner == kk) break;
+            slot_i = slot_i + 1 == (unsigned)R ? 0 : slot_i + 1;
+        }
+        atomicMin(&first[slot_i], k);
+        key[k] = -(int)slot_i - 1;  // remember the slot (negative marks "resolved")
+    }
+    __syncthreads();
+    // (3) group ids in order of the first member: leaders are the list positions k with first[slot(k)] == k
+    int carry = 0;
+    for (int base = 0; base < R; base += MG_THREADS) {
+        const int k = base + threadIdx.x;
+        int leader = 0;
+        if (k < R && key[k] < 0) leader = first[-key[k] - 1] == k;
+        int total;
+        const int ex = block_exclusive_scan1024(leader, &total, wsum);
+        if (leader) {
+            const int g = carry + ex + 1;
+            gof[k] = g;
+            gid[-key[k] - 1] = g;  // the slot's key is not needed any more: it now holds the group id for the members
+            long long *t = gs + (int64_t)(g - 1) * 8;
+            t[0] = 0; t[1] = 0; t[2] = 0; t[3] = H; t[4] = W; t[5] = 0; t[6] = 0; t[7] = 0;
+        }
+        carry += total;
+    }
+    __syncthreads();  // (group ids and the zeroed rows of this block's groups: written above, used below by the same block)
+    // (4) members take their leader's id; every listed region adds itself to its group's row (tiff_analysis.py:855-872)
+    for (int k = threadIdx.x; k < R; k += MG_THREADS) {
+        int g = 0;
+        if (key[k] < 0) g = gid[-key[k] - 1];
+        gof[k] = g;
+        if (g <= 0) continue;
+        const long long *sr = st + (int64_t)lst[k] * 8;
+        long long *t = gs + (int64_t)(g - 1) * 8;
+        atomicAdd((unsigned long long *)&t[0], (unsigned long long)sr[0]);
+        atomicAdd((unsigned long long *)&t[1], (unsigned long long)sr[1]);
+        atomicAdd((unsigned long long *)&t[2], (unsigned long long)sr[2]);
+        atomicMin(&t[3], sr[3]);
+        atomicMin(&t[4], sr[4]);
+        atomicMax(&t[5], sr[5]);
+        atomicMax(&t[6], sr[6]);
+        atomicAdd((unsigned long long *)&t[7], 1ull);
+    }
+    if (threadIdx.x == 0) n_groups[b] = carry;
+}
+
 // ---- A3 tail + A4: the reference's per-region loop (tiff_analysis.py:754-781) and the region lists that
 // get_cell_clusters_from_distances builds (:794-796, 811, 820) for one frame per block.
 constexpr int CLS_T = 4;  // cell-type slots (the reference has 3: CELL_TYPES)
@@ -785,6 +916,30 @@ int pcseg_merge_groups_runs(const uint32_t *dilated_bits, const int32_t *run_par
                  (const long long *)stats, region_list, n_list, key, H, W, cap, list_cap, 1, (const unsigned *)dilated_bits);
     PCSEG_CHECK_LAUNCH();
     PCSEG_LAUNCH(merge_groups_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, n_list, group_of, n_groups, key, first, gid, list_cap);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+int pcseg_merge_groups_fused(const uint32_t *dilated_bits, const int32_t *run_parent, const int64_t *stats,
+                             const int32_t *region_lists, const int32_t *n_lists, int slot, int n_slots, int32_t *group_of,
+                             int32_t *n_groups, int64_t *group_stats, int B, int H, int W, int cap, void *workspace,
+                             size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(dilated_bits && run_parent && stats && region_lists && n_lists && group_of && n_groups && group_stats &&
+                      workspace && cap >= 1 && n_slots >= 1 && slot >= 0 && slot < n_slots && check_shape(B, H, W),
+                  "bad arguments");
+    const int list_cap = cap;
+    Carver cv(workspace, workspace_bytes);
+    int *key = cv.take<int>((size_t)B * list_cap);
+    int *gid = cv.take<int>((size_t)B * list_cap);
+    int *first = cv.take<int>((size_t)B * (list_cap + 1));
+    if (!cv.ok()) {
+        set_error("merge_groups_fused: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    PCSEG_LAUNCH(merge_fused_kernel, dim3(B), dim3(MG_THREADS), 0, (hipStream_t)stream, (const unsigned *)dilated_bits,
+                 (const int *)run_parent, (const long long *)stats, (const int *)region_lists, (const int *)n_lists, slot, n_slots,
+                 (int *)group_of, (int *)n_groups, (long long *)group_stats, key, first, gid, H, W, cap, list_cap);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

@@ -39,6 +39,10 @@ static size_t g_used = 0;
 LaunchTimer::LaunchTimer(const char *n, const char *where, hipStream_t s) : stream(s), stop(nullptr)
 {
     if (!g_timing.load(std::memory_order_relaxed)) return;
+    {   // a stream that is being captured into a hipGraph takes no timing events (they would become graph nodes)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;
+    }
     hipEvent_t start;
     {
         std::lock_guard<std::mutex> lk(g_tmutex);

@@ -15,6 +15,10 @@ namespace pcseg {
 
 constexpr int TB_SLOTS = 5;  // CLS_T cell-type slots + the "combined" list
 
+struct ClassSlots {
+    uint8_t slot[256];  // class value -> cell-type slot, 255 = not a cell type
+};
+
 __device__ __forceinline__ int tb_block_scan(int v, int *total, int *wsum)
 {
     const int lane = lane_id(), wid = threadIdx.x >> 6;
@@ -213,6 +217,51 @@ __global__ void __launch_bounds__(256) table_write_kernel(pcseg_table_inputs in,
     }
 }
 
+// C14 for a whole batch (.m:260-268): for every cell / cluster row of type slot 0 or 1, the distance to the nearest row of
+// the OTHER of the two types in the same frame, over the dense `cells` table that table_write_kernel has just written
+// (rows of a frame are contiguous: offsets / counts of pcseg_table_layout).  Positions as MATLAB reports them:
+// (x, y) = (centroid_col + 1, centroid_row + 1).  pdist2 + min: sqrt(min over the other set of dx^2 + dy^2), each product
+// and the sum rounded on their own (no fused multiply-add), then / (512 / raster).  One block per frame; a frame lists a
+// few hundred rows, every thread scans the frame's rows of the other type.  NaN marks a row that has no entry in the
+// distance table (another type, or a frame in which one of the two types is absent).
+__global__ void __launch_bounds__(256) cell_distance_kernel(const double *__restrict__ cells, int ncol, const long long *__restrict__ counts,
+                                                             const long long *__restrict__ offsets, ClassSlots slots, double scale,
+                                                             double *__restrict__ dist)
+{
+    __shared__ int s_n[2];
+    const int b = blockIdx.x;
+    const long long row0 = offsets[b * 3 + 1];
+    const int n = (int)counts[b * 3 + 1];
+    const double *rows = cells + row0 * ncol;
+    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int sl = slots.slot[(int)rows[(int64_t)i * ncol + 2] & 255];
+        if (sl < 2) atomicAdd(&s_n[sl], 1);
+    }
+    __syncthreads();
+    const bool both = s_n[0] > 0 && s_n[1] > 0;
+    const double nan = __longlong_as_double(0x7FF8000000000000LL);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double *ri = rows + (int64_t)i * ncol;
+        const int sl = slots.slot[(int)ri[2] & 255];
+        double out = nan;
+        if (both && sl < 2) {
+            const double x = ri[6] + 1.0, y = ri[5] + 1.0;
+            double best = __longlong_as_double(0x7FF0000000000000LL);
+            for (int j = 0; j < n; ++j) {
+                const double *rj = rows + (int64_t)j * ncol;
+                if (slots.slot[(int)rj[2] & 255] != 1 - sl) continue;
+                const double dx = x - (rj[6] + 1.0), dy = y - (rj[5] + 1.0);
+                const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+                best = d2 < best ? d2 : best;
+            }
+            out = __ddiv_rn(__dsqrt_rn(best), scale);
+        }
+        dist[row0 + i] = out;
+    }
+}
+
 }  // namespace pcseg
 
 using namespace pcseg;
@@ -266,6 +315,26 @@ int pcseg_table_write(const pcseg_table_inputs *in, double *rois, double *cells,
     }
     PCSEG_LAUNCH(table_write_kernel, dim3(in->B), dim3(256), 0, (hipStream_t)stream, *in, (const long long *)offsets, rois, cells,
                  groups, (long long *)frames, own, comb);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+int pcseg_cell_distances(const double *cells, int64_t n_rows, int ncol, const uint8_t *class_slot, double raster, double size,
+                         double *dist, int B, const void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(cells && class_slot && dist && workspace && B >= 1 && ncol >= 14 && n_rows >= 0 && raster > 0.0 && size > 0.0,
+                  "bad arguments");
+    Carver cv(const_cast<void *>(workspace), workspace_bytes);
+    const long long *counts = cv.take<long long>(3 * (size_t)B);
+    const long long *offsets = cv.take<long long>(3 * (size_t)B);
+    if (!cv.ok()) {
+        set_error("cell_distances: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    ClassSlots slots;
+    memcpy(slots.slot, class_slot, 256);
+    PCSEG_LAUNCH(cell_distance_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cells, ncol, counts, offsets, slots, size / raster,
+                 dist);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

@@ -97,7 +97,7 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
     rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     mine = shard_frames(n_frames, rank, world)
-    ratio_kw = {"ratios": table_kwargs["ratios"]} if "ratios" in table_kwargs else {}
+    ratio_kw = {k: table_kwargs[k] for k in ("ratios", "distances", "raster") if k in table_kwargs}
     parts = []
     pending = collections.deque()
     depth = max(1, int(getattr(pipe, "lanes", 1)))  # batches the pipeline keeps in flight: a table is assembled (which
@@ -107,6 +107,12 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
         frames = make_batch(ids)
         if not seen_planes and hasattr(frames, "shape") and len(frames.shape) == 4:
             seen_planes = int(frames.shape[1])
+        # a graph-mode pipeline keeps `lanes` results alive (a lane's next replay overwrites its previous result): the
+        # oldest batch's tables are taken BEFORE the batch that reuses its lane is handed over -- the wait for it runs
+        # under the other lanes' kernels
+        while getattr(pipe, "graph", False) and len(pending) >= depth:
+            res, rid = pending.popleft()
+            parts.append(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
         pending.append((pipe.run(frames), ids))
         if len(pending) > depth:
             res, rid = pending.popleft()
@@ -119,7 +125,7 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
     if parts:
         merged = {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
     else:
-        merged = pipe.empty_device_tables(planes, device=device, **ratio_kw)
+        merged = pipe.empty_device_tables(planes, device=device, **({"ratios": ratio_kw["ratios"]} if "ratios" in ratio_kw else {}))
     # (a rank's own rows come out of the batches in frame order, labels ascending: with one rank that IS the gathered
     # order and the sort is skipped)
     gathered = gather_tables(merged, device=device, group=group, presorted=world == 1 and mine == sorted(mine))

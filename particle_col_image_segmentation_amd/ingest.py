@@ -34,16 +34,25 @@ class FrameUploader:
         self.copied = [torch.cuda.Event() for _ in range(self.depth)]  # "the copy out of pinned buffer k has finished"
         self.bytes_uploaded = 0
 
-    def upload_staged(self, stage):
+    def upload_staged(self, stage, out=None):
         """Asynchronous copy of a batch that already sits in pinned host memory (a reader that decodes straight into
         pinned buffers): returns the device tensor, readable by the caller's current stream; the caller must not
-        overwrite ``stage`` before the returned event has completed.  Returns (device stack, copy-finished event)."""
+        overwrite ``stage`` before the returned event has completed.  ``out``: a device buffer to refill instead of a
+        fresh allocation (``FramePipeline(graph=True)`` keys its graphs on the input buffer, so a dataset run refills a
+        few fixed buffers in turn); the caller makes ``copy_stream`` wait for whatever still reads it.
+        Returns (device stack, copy-finished event)."""
         if not stage.is_pinned():
             raise ValueError("upload_staged needs pinned host memory")
         consumer = torch.cuda.current_stream(self.device)
         done = torch.cuda.Event()
         with torch.cuda.stream(self.copy_stream):
-            dev = torch.empty(tuple(stage.shape), dtype=stage.dtype, device=self.device)
+            if out is None:
+                dev = torch.empty(tuple(stage.shape), dtype=stage.dtype, device=self.device)
+            else:
+                if tuple(out.shape) != tuple(stage.shape) or out.dtype != stage.dtype or not out.is_cuda:
+                    raise ValueError("upload_staged: `out` must be a device tensor of the staging buffer's shape and dtype")
+                self.copy_stream.wait_stream(consumer)  # whatever the caller's stream last did with the buffer
+                dev = out
             dev.copy_(stage, non_blocking=True)
             done.record(self.copy_stream)
         consumer.wait_event(done)

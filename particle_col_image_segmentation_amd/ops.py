@@ -322,6 +322,34 @@ def merge_groups_runs(bits, run_parent, stats, region_list, n_list):
     return group_of, n_groups
 
 
+def merge_groups_fused(bits, run_parent, stats, region_lists, n_lists, slot):
+    """get_merged_regions grouping + the member sums of the groups (tiff_analysis.py:843-878) for type slot ``slot`` in
+    one launch: ``region_lists`` int32 (B, n_slots, cap) / ``n_lists`` int32 (B, n_slots) as classify_regions returns
+    them.  Returns (group_of int32 (B,cap), n_groups int32 (B,), group_stats int64 (B,cap,8)); entries beyond a frame's
+    list length / group count are not initialised."""
+    bits = _req(bits, torch.int32, 3)
+    run_parent = _req(run_parent, torch.int32, 3)
+    stats = _req(stats, torch.int64, 3)
+    region_lists = _req(region_lists, torch.int32, 3)
+    n_lists = _req(n_lists, torch.int32, 2)
+    B, H, W = run_parent.shape
+    cap = stats.shape[1]
+    n_slots = region_lists.shape[1]
+    if region_lists.shape[2] != cap or tuple(n_lists.shape) != (B, n_slots):
+        raise ValueError("region lists of shape %s / %s do not match the region table" % (tuple(region_lists.shape), tuple(n_lists.shape)))
+    dev = stats.device
+    lib = _lib.load()
+    group_of = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    n_groups = torch.empty((B,), dtype=torch.int32, device=dev)
+    gstats = torch.empty((B, cap, 8), dtype=torch.int64, device=dev)
+    nbytes = lib.pcseg_merge_groups_workspace_bytes(B, cap)
+    ws = _ws(nbytes, dev)
+    _lib.check(lib.pcseg_merge_groups_fused(_ptr(bits), _ptr(run_parent), _ptr(stats), _ptr(region_lists), _ptr(n_lists), int(slot),
+                                            n_slots, _ptr(group_of), _ptr(n_groups), _ptr(gstats), B, H, W, cap, _ptr(ws), nbytes,
+                                            _stream()), "merge_groups_fused")
+    return group_of, n_groups, gstats
+
+
 def merge_groups(dilated_labels, stats, region_list, n_list, roots=False):
     """get_merged_regions grouping (tiff_analysis.py:843-878): group id per list entry, 0 = dropped.
     roots=True: `dilated_labels` is the parent image of dilated_roots()."""
@@ -415,8 +443,10 @@ def classify_regions(stats, cls_out, counts, tables):
     return out
 
 
-def build_tables(res, groups, frame_ids, C, ratios, check=False):
-    """csrc/tables.hip: dense row tables of one batch (see FramePipeline.tables_device)."""
+def build_tables(res, groups, frame_ids, C, ratios, check=False, distance_slots=None, raster=19.0):
+    """csrc/tables.hip: dense row tables of one batch (see FramePipeline.tables_device).  ``distance_slots``: the
+    class value -> type slot table (uint8[256] numpy); with it the result carries ``cell_dist`` (one value per row of
+    ``cells``, NaN = no entry) of pcseg_cell_distances."""
     lib = _lib.load()
     B, cap = res["stats"].shape[0], res["stats"].shape[1]
     dev = res["stats"].device
@@ -479,7 +509,13 @@ def build_tables(res, groups, frame_ids, C, ratios, check=False):
     frames = torch.empty((B, 17), dtype=torch.int64, device=dev)
     _lib.check(lib.pcseg_table_write(ctypes.byref(ti), _ptr(rois), _ptr(cells), _ptr(grp), _ptr(frames), _ptr(ws), nbytes,
                                      _stream()), "table_write")
-    return {"rois": rois[:n_roi], "cells": cells[:n_cell], "groups": grp[:n_group], "frames": frames, "frame_ids": frame_ids}
+    out = {"rois": rois[:n_roi], "cells": cells[:n_cell], "groups": grp[:n_group], "frames": frames, "frame_ids": frame_ids}
+    if distance_slots is not None:
+        dist = torch.empty((n_cell + 1,), dtype=torch.float64, device=dev)
+        _lib.check(lib.pcseg_cell_distances(_ptr(cells), n_cell, cells.shape[1], ctypes.c_void_p(distance_slots.ctypes.data),
+                                            float(raster), 512.0, _ptr(dist), B, _ptr(ws), nbytes, _stream()), "cell_distances")
+        out["cell_dist"] = dist[:n_cell]
+    return out
 
 
 def remove_overlapping(dapi, other, threshold):

@@ -9,10 +9,10 @@ that is already resident in HBM:
     -> boundary refinement: threshold + EDT + local maxima + markers + watershed (R1-R4, W1)
     -> per-ROI isotope sums of the refined ROIs (M1)
 
-Everything stays on the device; the only host synchronisations are the
-watershed's convergence polls.  ``tables()`` downloads the result as plain numpy
-tables (the per-ROI table format of this build; the reference's CSV writers take
-the per-frame drop-in objects instead, see ``tiff_analysis``).
+Everything stays on the device and no kernel chain waits for the host (the watershed's fixed points finish in
+device-side tail kernels), so the whole chain of a batch can be captured once as a hipGraph and replayed
+(``FramePipeline(graph=True)``).  ``tables()`` downloads the result as plain numpy tables (the per-ROI table format of
+this build; the reference's CSV writers take the per-frame drop-in objects instead, see ``tiff_analysis``).
 """
 import numpy as np
 import torch
@@ -34,8 +34,25 @@ class BatchResult(dict):
     next batch's class-map chain running under this batch's watershed tail."""
 
     _pending = None
+    _slot = None   # graph mode: the capture slot whose static tensors this result aliases ...
+    _gen = 0       # ... and the slot's replay count when this result was handed out
+
+    def _check_alive(self):
+        if self._slot is not None and self._slot.gen != self._gen:
+            raise RuntimeError("this graph-mode result has been overwritten: its lane has replayed a later batch "
+                               "(results stay valid until `lanes` further batches have been handed to run())")
+
+    def done_events(self):
+        """The events that close this batch's kernel chains (waits for the lane thread to have enqueued them)."""
+        pending = self._pending
+        if pending is None:
+            return []
+        if hasattr(pending, "result"):
+            return list(pending.result()[1])
+        return list(pending)
 
     def synchronize(self):
+        self._check_alive()
         pending = self._pending
         if pending is None:
             return self
@@ -49,16 +66,19 @@ class BatchResult(dict):
         # the tensors were allocated on the lane's streams: tell the caching allocator that the caller's stream uses
         # them too, so that dropping this result cannot hand their blocks to the lane's next batch while a kernel the
         # caller enqueued is still reading them
-        cur = torch.cuda.current_stream()
-        for t in _tensors(dict.values(self)):
-            if t.is_cuda:
-                t.record_stream(cur)
+        if self._slot is None:  # (a graph slot's tensors live in the graph's private pool: nothing to announce)
+            cur = torch.cuda.current_stream()
+            for t in _tensors(dict.values(self)):
+                if t.is_cuda:
+                    t.record_stream(cur)
         self._pending = None
         return self
 
     def __getitem__(self, key):
         if self._pending:
             self.synchronize()
+        elif self._slot is not None:
+            self._check_alive()
         return dict.__getitem__(self, key)
 
     def get(self, key, default=None):
@@ -157,9 +177,26 @@ def _on(stream, *tensors):
             t.record_stream(stream)
 
 
+class _GraphSlot:
+    """One captured chain: the hipGraph of a lane for one input buffer, the static result tensors it writes (they live in
+    the graph's private memory pool) and the stream it is replayed on."""
+    __slots__ = ("graph", "entries", "stream", "release", "gen", "stack")
+
+    def __init__(self, stream):
+        self.graph, self.entries, self.stream, self.release, self.gen, self.stack = None, None, stream, None, 0, None
+
+
 class FramePipeline:
     def __init__(self, cell_types=None, threshold=0.5, boundary_plane=BOUNDARY_PLANE, cap=None, merged=True,
-                 watershed_mode=0, overlap=True, lanes=8, multi_stream=True):
+                 watershed_mode=0, overlap=True, lanes=None, multi_stream=True, graph=False, max_graphs=None):
+        """``graph=True``: the chain of a batch (about a hundred launches on five streams) is captured ONCE per input
+        buffer as a hipGraph and replayed for every later batch in that buffer -- one host call per batch instead of a
+        hundred, no host thread per lane.  Inputs must then live in a small set of reused device buffers (the graph is
+        keyed on the buffer's address and shape; ``max_graphs`` bounds the cache), and a result's tensors are the
+        graph's static outputs: they stay valid until ``lanes`` further batches have been handed to :meth:`run`.
+        ``lanes``: batches in flight (default 8 host threads in eager mode, 2 replay streams in graph mode)."""
+        if lanes is None:
+            lanes = 2 if graph else 8
         self.cell_types = dict(cell_types or CELL_TYPES_5)
         self.tables_ = ops.ClassTables(self.cell_types, ta.CELL_TYPES, ta.MIN_CELL_AREA, ta.MIN_CLUSTER_AREA)
         self.threshold = float(threshold)
@@ -170,6 +207,9 @@ class FramePipeline:
         self.overlap = overlap
         self.lanes = max(1, int(lanes))
         self.multi_stream = bool(multi_stream)  # False: the class-map chain (incl. merges and fill) on ONE stream
+        self.graph = bool(graph)
+        self.max_graphs = int(max_graphs or 4 * self.lanes)
+        self._graphs = {}  # (lane, input address, shape) -> _GraphSlot, in insertion order (oldest first)
         self._table_stream = None
         self._lane_pool = None  # one single-thread executor + stream set per lane, made on first use
         self._lane_streams = None
@@ -181,6 +221,8 @@ class FramePipeline:
         ``result.synchronize()`` has returned: the kernels read it asynchronously."""
         if stack.dim() != 4 or stack.dtype != torch.float32 or not stack.is_cuda:
             raise TypeError("stack must be a (B, C, H, W) float32 CUDA tensor")
+        if self.graph:
+            return self._run_graph(stack)
         stack = stack.contiguous()
         res = BatchResult()
         res["shape"] = tuple(stack.shape)
@@ -213,6 +255,69 @@ class FramePipeline:
             pool.submit(lambda: None).result()
         torch.cuda.synchronize()
 
+    # ------------------------------------------------------------------ hipGraph capture / replay
+    def _run_graph(self, stack):
+        if not stack.is_contiguous():
+            raise ValueError("graph mode needs a contiguous input buffer (the graph is keyed on its address)")
+        dev = stack.device
+        lane = self._step % self.lanes
+        self._step += 1
+        key = (lane, stack.data_ptr(), tuple(stack.shape))
+        slot = self._graphs.get(key)
+        if slot is None:
+            slot = self._capture(lane, stack, key)
+        cur = torch.cuda.current_stream(dev)
+        slot.stream.wait_stream(cur)  # whatever the caller's stream wrote into the buffer
+        if slot.release is not None:  # ... and whoever still reads the slot's previous result (tables_device)
+            slot.stream.wait_event(slot.release)
+            slot.release = None
+        done = torch.cuda.Event()
+        with torch.cuda.stream(slot.stream):
+            slot.graph.replay()
+            done.record(slot.stream)
+        slot.gen += 1
+        res = BatchResult(slot.entries)
+        res._pending, res._slot, res._gen = [done], slot, slot.gen
+        return res
+
+    def _capture(self, lane, stack, key):
+        """Capture the lane's five-stream chain for this input buffer (once).  A plain run comes first: one-time work
+        inside the library (function attributes, the tile counter's allocation) must not fall into the capture."""
+        dev = stack.device
+        while len(self._graphs) >= self.max_graphs:
+            self._graphs.pop(next(iter(self._graphs)))  # oldest first; its memory pool goes with it
+        _, lane_streams = _lanes_for(dev, self.lanes)
+        streams = lane_streams[lane]
+        slot = _GraphSlot(torch.cuda.Stream(device=dev))
+        entries = {"shape": tuple(stack.shape)}
+
+        def chain(s_main):
+            ready = torch.cuda.Event()
+            ready.record(s_main)
+            if self.overlap:
+                out, done = self._run_streams(streams, stack, ready, dict(entries))
+                for ev in done:
+                    s_main.wait_event(ev)
+                return out
+            out = BatchResult(entries)
+            self._class_stage(stack, out)
+            for sl in self._merge_slots():
+                self._merge_stage(stack, out, sl)
+            self._fill_stage(stack, out)
+            self._refine_chain(stack, out)
+            return dict(out)
+
+        slot.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(slot.stream):
+            chain(slot.stream)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=slot.stream, capture_error_mode="thread_local"):
+            slot.entries = chain(slot.stream)
+        slot.graph, slot.stack = graph, stack  # (the buffer stays alive as long as a graph reads it)
+        self._graphs[key] = slot
+        return slot
+
     def _merge_slots(self):
         if not self.merged:
             return []
@@ -220,8 +325,10 @@ class FramePipeline:
 
     def _run_lane(self, lane, stack, ready, entries):
         torch.cuda.set_device(stack.device)
+        return self._run_streams(self._lane_streams[lane], stack, ready, entries)
+
+    def _run_streams(self, streams, stack, ready, entries):
         out = BatchResult(entries)  # built privately: the caller's object only receives it on synchronize()
-        streams = self._lane_streams[lane]
         s_class, s_refine, s_fill, s_m1, s_m2 = streams
         if not self.multi_stream:
             s_fill = s_m1 = s_m2 = s_class
@@ -290,10 +397,7 @@ class FramePipeline:
         # dilated components as a union-find over the vertical runs of the 1-bit image: grouping only needs "same
         # component" at the centroid pixels, so no label image is ever written
         dbits, run_par = ops.dilated_runs(res["denoised"], bits, ta.CELL_CLUSTER_DISTANCE_THRESHOLD // 2)
-        lst = res["region_list"][:, s].contiguous()
-        nl = res["n_list"][:, s].contiguous()
-        gof, ng = ops.merge_groups_runs(dbits, run_par, res["stats"], lst, nl)
-        gst = ops.group_reduce(res["stats"], lst, nl, gof, ng, H, W)
+        gof, ng, gst = ops.merge_groups_fused(dbits, run_par, res["stats"], res["region_list"], res["n_list"], s)
         res["groups"][s] = {"group_of": gof, "n_groups": ng, "group_stats": gst}
 
     def _fill_stage(self, stack, res):
@@ -339,11 +443,14 @@ class FramePipeline:
                        "max_row1", "max_col1", "members"],
         }
 
-    def tables_device(self, res, frame_ids=None, ratios=RATIOS_5, check=True):
+    def tables_device(self, res, frame_ids=None, ratios=RATIOS_5, check=True, distances=False, raster=19.0):
         """The batch as dense row tables, assembled ON THE DEVICE (``csrc/tables.hip``): float64 CUDA tensors ``rois``,
         ``cells``, ``groups`` and ``frames_rec`` (one row per frame: frame id + the int64 record of
         ``pcseg_table_write``, see include/pcseg.h).  One small device-to-host copy (three row totals) sizes the
-        outputs; nothing else leaves the GPU, so the tables can go straight into the all-gather."""
+        outputs; nothing else leaves the GPU, so the tables can go straight into the all-gather.  ``distances``: also the
+        nearest-other-type table of BASELINE config 5 (.m:260-268) as ``distances`` = ``[frame, label, distance]`` -- one
+        batched launch over the cell rows of every frame (rows of type slot 0, then of slot 1, inside each frame); always
+        present (empty unless requested) so that every rank gathers the same set of tables."""
         res.synchronize()
         B, C, H, W = res["shape"]
         dev = res["stats"].device
@@ -361,29 +468,55 @@ class FramePipeline:
             else:
                 fid = torch.tensor(ids, dtype=torch.int64).to(dev)
             groups = (res.get("groups") or {}) if self.merged else {}
-            dt = ops.build_tables(res, groups, fid, C, ratios, check=check)  # raises what BatchResult.check() raises
+            dt = ops.build_tables(res, groups, fid, C, ratios, check=check,  # raises what BatchResult.check() raises
+                                  distance_slots=self.tables_.slot if distances else None, raster=raster)
             dt["frames_rec"] = torch.cat([fid[:, None].to(torch.float64), dt.pop("frames").to(torch.float64)], dim=1)
             del dt["frame_ids"]
+            dt["distances"] = self._distance_rows(dt["cells"], dt.pop("cell_dist", None))
+            if res._slot is not None:  # graph mode: the lane may overwrite this result once the tables are out
+                res._check_alive()
+                res._slot.release = torch.cuda.Event()
+                res._slot.release.record(ts)
         torch.cuda.current_stream(dev).wait_stream(ts)
         for t in dt.values():
             t.record_stream(torch.cuda.current_stream(dev))
         return dt
+
+    def _distance_rows(self, cells, cell_dist):
+        """``[frame, label, distance]`` for the rows of ``cells`` that have a distance, frame by frame the rows of type
+        slot 0, then those of slot 1 (the order in which the script concatenates its two ROI classes, .m:264-268)."""
+        if cell_dist is None or cells.shape[0] == 0:
+            return torch.zeros((0, 3), dtype=torch.float64, device=cells.device)
+        keep = torch.nonzero(~torch.isnan(cell_dist))[:, 0]
+        if keep.numel() == 0:
+            return torch.zeros((0, 3), dtype=torch.float64, device=cells.device)
+        rows = cells[keep]
+        lut = torch.from_numpy(self.tables_.slot.astype("int64")).to(cells.device)
+        slot = lut[rows[:, 2].to(torch.int64)]
+        # rows are in (frame position, label) order already: a STABLE sort by slot inside each frame keeps labels ascending
+        pos = torch.cumsum(torch.cat([rows.new_zeros(1), (rows[1:, 0] != rows[:-1, 0]).to(rows.dtype)]), 0).to(torch.int64)
+        order = torch.sort(pos * 2 + slot, stable=True)[1]
+        return torch.stack([rows[order, 0], rows[order, 1], cell_dist[keep][order]], dim=1)
 
     def empty_device_tables(self, C, ratios=RATIOS_5, device=None):
         """What :meth:`tables_device` returns for zero frames (a rank that owns no frame of a dataset)."""
         cols = self.table_columns(C, ratios)
         mk = lambda n: torch.zeros((0, n), dtype=torch.float64, device=device)
         return {"rois": mk(len(cols["rois"])), "cells": mk(len(cols["cells"])), "groups": mk(len(cols["groups"])),
-                "frames_rec": mk(18)}
+                "frames_rec": mk(18), "distances": mk(3)}
 
     def host_tables(self, dt, C, ratios=RATIOS_5, distances=False, raster=19.0):
-        """numpy tables from (downloaded or gathered) :meth:`tables_device` output: ``cells`` / ``rois`` / ``groups`` as
-        they are, ``frames`` after the two ``round(x, 5)`` of get_cell_counts_and_densities (tiff_analysis.py:1018-1038;
-        Python's decimal rounding, a handful of numbers per frame), ``distances`` on request (.m:260-268)."""
+        """numpy tables from (downloaded or gathered) :meth:`tables_device` output: ``cells`` / ``rois`` / ``groups`` /
+        ``distances`` as they are, ``frames`` after the two ``round(x, 5)`` of get_cell_counts_and_densities
+        (tiff_analysis.py:1018-1038; Python's decimal rounding, a handful of numbers per frame).  Every table's width
+        must be the one :meth:`table_columns` names for ``C`` planes and these ``ratios``."""
         host = _download(dt)
         cols = self.table_columns(C, ratios)
         tb = self.tables_
         out = {k: host[k] for k in ("cells", "rois", "groups")}
+        for k in out:
+            if out[k].shape[1] != len(cols[k]):
+                raise ValueError("table %r has %d columns, the schema for %d planes names %d" % (k, out[k].shape[1], C, len(cols[k])))
         rec = host["frames_rec"]
         px2 = ta.PX_TO_UM_CONV ** 2
         frame_rows = []
@@ -399,25 +532,10 @@ class FramePipeline:
                         round((area_px / px2) / pa_um, 5) if ok else nan]
             frame_rows.append(row)
         out["frames"] = np.array(frame_rows, np.float64).reshape(len(frame_rows), len(cols["frames"]))
-        dist_rows = []
-        if distances and torch.cuda.is_available():
-            # .m:260-268 per frame: nearest ROI of the other cell type for the cells / clusters of slots 0 and 1
-            cells = out["cells"]
-            slot = tb.slot[cells[:, 2].astype(np.int64)] if len(cells) else np.zeros(0, np.uint8)
-            dev = torch.device("cuda", torch.cuda.current_device())
-            for f in rec[:, 0]:
-                rows = cells[:, 0] == f
-                pos = {}
-                for s in (0, 1):
-                    sel = cells[rows & (slot == s)]
-                    pos[s] = (sel[:, 1], np.stack([sel[:, 6] + 1.0, sel[:, 5] + 1.0], axis=1))
-                if len(pos[0][0]) and len(pos[1][0]):
-                    ta_ = torch.from_numpy(np.ascontiguousarray(pos[0][1])).to(dev)
-                    tc_ = torch.from_numpy(np.ascontiguousarray(pos[1][1])).to(dev)
-                    da, dc = ops.nearest_dist(ta_, tc_).cpu().numpy(), ops.nearest_dist(tc_, ta_).cpu().numpy()
-                    for lab, d in list(zip(pos[0][0], da)) + list(zip(pos[1][0], dc)):
-                        dist_rows.append([f, lab, d / (512.0 / raster)])
-        out["distances"] = np.array(dist_rows, np.float64).reshape(-1, 3)
+        # the nearest-other-type table comes from the device (tables_device(distances=True)); without it an empty table
+        if distances and "distances" not in host:
+            raise ValueError("host_tables(distances=True) needs tables made by tables_device(..., distances=True)")
+        out["distances"] = host["distances"].reshape(-1, 3) if distances and "distances" in host else np.zeros((0, 3), np.float64)
         for k, v in cols.items():
             out[k + "_columns"] = v
         return out
@@ -429,4 +547,4 @@ class FramePipeline:
         flags itself, e.g. to keep the ROI rows of a batch in which the reference would have raised on one frame's
         cluster statistics)."""
         C = res["shape"][1]
-        return self.host_tables(self.tables_device(res, frame_ids, ratios, check), C, ratios, distances, raster)
+        return self.host_tables(self.tables_device(res, frame_ids, ratios, check, distances, raster), C, ratios, distances, raster)

@@ -180,3 +180,44 @@ def test_batches_in_flight_do_not_interfere():
             np.testing.assert_allclose(res["ws_sums"][b, :m].cpu().numpy(), ref["ws_sums"][b, :m].cpu().numpy(), rtol=1e-9, atol=1e-9)
     pipe.synchronize()
 
+
+
+def test_graph_mode_replays_equal_eager_runs():
+    """FramePipeline(graph=True): the five-stream chain captured once per (lane, input buffer) as a hipGraph and
+    replayed.  Different data copied into the same two buffers must give what the eager single-stream pipeline gives
+    (bit-exact integers; plane sums to the float64 atomics' reordering), through the dense tables too; a result whose
+    lane has replayed a later batch refuses to be read."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from particle_col_image_segmentation_amd import synth
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline
+    ct = dict(synth.CELL_TYPES_5)
+    data = [torch.from_numpy(synth.gen_batch(7300 + 10 * k, 5, 160, 224, ties=(k % 3 == 1))).cuda() for k in range(5)]
+    bufs = [torch.empty_like(data[0]) for _ in range(2)]
+    pipe = FramePipeline(ct, graph=True, lanes=2)
+    solo = FramePipeline(ct, overlap=False)
+    keys = ("denoised", "labels", "counts", "recreated", "overlap_area", "markers", "n_markers", "ws_labels", "tie_flags",
+            "kind", "cells", "nan_flag")
+    results = []
+    for k, st in enumerate(data):
+        bufs[k % 2].copy_(st)
+        res = pipe.run(bufs[k % 2])
+        results.append(res)
+        ref = solo.run(st)
+        torch.cuda.synchronize()
+        for key in keys:
+            assert torch.equal(res[key], ref[key]), (k, key)
+        for b in range(st.shape[0]):
+            n, m = int(ref["counts"][b]), int(ref["n_markers"][b])
+            assert torch.equal(res["stats"][b, :n], ref["stats"][b, :n])
+            assert torch.equal(res["ws_stats"][b, :m], ref["ws_stats"][b, :m])
+            np.testing.assert_allclose(res["ws_sums"][b, :m].cpu().numpy(), ref["ws_sums"][b, :m].cpu().numpy(), rtol=1e-9, atol=1e-9)
+        tg = pipe.tables(res, check=False)
+        te = solo.tables(ref, check=False)
+        for name in ("rois", "cells", "groups", "frames"):
+            np.testing.assert_allclose(tg[name], te[name], rtol=1e-9, atol=0, equal_nan=True, err_msg="%d %s" % (k, name))
+    assert len(pipe._graphs) == 2  # one capture per (lane, buffer); five batches, two graphs
+    with pytest.raises(RuntimeError, match="overwritten"):
+        results[0]["labels"]
+    results[-1]["labels"]  # the newest result of each lane is still readable
+    results[-2]["labels"]

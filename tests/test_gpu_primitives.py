@@ -373,6 +373,24 @@ def test_merge_groups(ops):
         np.testing.assert_array_equal(unpacked.astype(bool), host(dil)[i].astype(bool))
     g3, n3 = ops.merge_groups_runs(dbits, run_par, stats, dev(rl), n_list)
     assert torch.equal(g3, group_of) and torch.equal(n3, n_groups)
+    # the one-launch form the pipeline runs (keys + grouping + member sums, lists read in place from the (B, slots, cap)
+    # arrays of classify_regions): same groups, and the group rows equal pcseg_group_reduce's
+    tab_cap = stats.shape[1]
+    rls = np.full((2, 3, tab_cap), -7, np.int32)   # the list sits in slot 1 of 3; the other slots hold garbage
+    nls = np.array([[5, 0, 9], [5, 0, 9]], np.int32)
+    for i, l in enumerate(lists):
+        rls[i, 1, :len(l)] = l
+        nls[i, 1] = len(l)
+    gf, nf, gsf = ops.merge_groups_fused(dbits, run_par, stats, dev(rls), dev(nls), 1)
+    rl_full = np.full((2, tab_cap), -1, np.int32)
+    rl_full[:, :min(cap, tab_cap)] = rl[:, :min(cap, tab_cap)]
+    g4, n4 = ops.merge_groups_runs(dbits, run_par, stats, dev(rl_full), n_list)
+    gs4 = ops.group_reduce(stats, dev(rl_full), n_list, g4, n4, 160, 160)
+    assert torch.equal(nf, n_groups)
+    for i in range(2):
+        k, ng = len(lists[i]), int(n_groups[i])
+        assert torch.equal(gf[i, :k], group_of[i, :k])
+        assert torch.equal(gsf[i, :ng], gs4[i, :ng])
     for rad in (0, 1, 3, 5):
         rr = ops.dilated_roots(dev(cm), 1 << 1, rad)
         for i in range(2):

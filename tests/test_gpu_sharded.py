@@ -81,7 +81,7 @@ def test_sharded_fixture_is_what_the_pipeline_produces():
     for k in stored.files:
         if k.endswith("_columns"):
             assert list(stored[k]) == list(fresh[k])
-        elif k in ("cells", "rois"):  # float64 atomics: plane sums may differ in the last bits between runs
+        elif k in ("cells", "rois", "distances"):  # float64 atomics: plane sums may differ in the last bits between runs
             np.testing.assert_allclose(fresh[k], stored[k], rtol=1e-12, atol=0)
         else:
             np.testing.assert_array_equal(fresh[k], stored[k])
@@ -102,3 +102,21 @@ def test_sharded_fixture_is_what_the_pipeline_produces():
                      [(r.label, 2, r.area, r.cells) for rs in ref["cell_clusters"].values() for r in rs])
         assert [(int(r[1]), int(r[3]), int(r[4]), int(r[11])) for r in crow] == exp
     assert checked >= mod.N_FRAMES // 2
+    # the batched device distance table (.m:260-268; PARITY UNPINNED: no MATLAB here) against the oracle's restatement,
+    # frame by frame from the positions the cells table holds: rows of type slot 0, then of slot 1
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline
+    slot = FramePipeline(ct).tables_.slot
+    n_dist = 0
+    for i in range(mod.N_FRAMES):
+        crow = fresh["cells"][fresh["cells"][:, 0] == i]
+        sl = slot[crow[:, 2].astype(np.int64)]
+        a, b = crow[sl == 0], crow[sl == 1]
+        drow = fresh["distances"][fresh["distances"][:, 0] == i]
+        if len(a) == 0 or len(b) == 0:
+            assert len(drow) == 0
+            continue
+        exp = orc.nearest_distances(np.stack([a[:, 6] + 1.0, a[:, 5] + 1.0], 1), np.stack([b[:, 6] + 1.0, b[:, 5] + 1.0], 1))
+        np.testing.assert_array_equal(drow[:, 1], np.concatenate([a[:, 1], b[:, 1]]))
+        np.testing.assert_allclose(drow[:, 2], exp, rtol=1e-12, atol=0)
+        n_dist += len(drow)
+    assert n_dist > 20
