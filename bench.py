@@ -35,7 +35,7 @@ CHAIN_BYTES_PER_PIXEL = 28  # 5 x f32 in + int32 class-CC mask +
 KERNEL_BYTES_PER_PIXEL = {
     "classmap_median_ccl_kernel": 26.0, "ccl_flatten_count_kernel": 4.0, "ccl_relabel_kernel": 8.0,
     "region_reduce_col_kernel": 24.0, "edt_bits_kernel": 5.125, "edt_row_kernel": 4.0, "edt_reach_kernel": 2.0,
-    "locmax_candidates_kernel": 13.0, "locmax_propagate_kernel": 5.0,
+    "locmax_candidates_kernel": 8.25,
     "ws_relax_kernel": 12.0, "ws_uf_tile_kernel": 13.0, "ws_uf_label4_kernel": 9.0, "ws_exact_kernel": 21.0,
 }
 

@@ -49,6 +49,22 @@ struct KeyI32 {
     int64_t n;
     __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + (int64_t)r * W + c]; }
 };
+// candidate pixels of the local-maxima pass: one bit per pixel in a FLAT bit array over the batch (bit b * n + r * W + c),
+// key = the pixel's value where the bit is set (0 -> INT_MIN: keys must be non-zero), 0 elsewhere
+__device__ __forceinline__ bool cand_bit(const unsigned long long *bits, int64_t g) { return (bits[g >> 6] >> (g & 63)) & 1ull; }
+struct KeyCandBits {
+    const int32_t *img;
+    const unsigned long long *bits;
+    int W;
+    int64_t n;
+    __device__ __forceinline__ int operator()(int b, int r, int c) const
+    {
+        const int64_t g = b * n + (int64_t)r * W + c;
+        if (!cand_bit(bits, g)) return 0;
+        const int v = img[g];
+        return v == 0 ? (int)0x80000000 : v;
+    }
+};
 struct KeyBits {  // 1 bit per pixel in 32-row column words: words[(b * nch + r / 32) * W + c] bit (r % 32)
     const unsigned *words;
     int W, nch;
@@ -641,9 +657,15 @@ constexpr int LM_TW = CCL_TW, LM_TH = CCL_TH, LM_SW = LM_TW + 4, LM_SH = LM_TH +
 // ... and the union-find tile pass of the candidates' plateaus (equal-valued 8-connected candidates) runs in the same
 // kernel on the keys while they are still in LDS: the key image is written for the border pass but never read back
 // by a tile pass of its own.
-__global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__restrict__ img, int *__restrict__ key_out,
+// What leaves the kernel is SPARSE: candidates are a few per cent of a distance map, so instead of a key image, a flag
+// image and a parent image (9 bytes per pixel, each read back by one or two later passes) the kernel writes one bit per
+// pixel (flat bit array, see cand_bit) and the parent / flag entries of the candidate pixels only; every later pass
+// (border links, flag propagation, root count, relabel) walks the bit words and touches candidates only.  With
+// `markers` the kernel also zero-fills the marker image at the non-candidates: the relabel pass then writes the
+// candidates, and every pixel of the output is written exactly once.
+__global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__restrict__ img, unsigned long long *__restrict__ cbits,
                                                                  uint8_t *__restrict__ bad, int *__restrict__ nonconst,
-                                                                 int *__restrict__ parent, int H, int W)
+                                                                 int *__restrict__ parent, int *__restrict__ markers, int H, int W)
 {
     __shared__ int tile[LM_SH * LM_SW];
     __shared__ uint8_t cand[LM_CH * LM_CW];  // tile + 1 ring: 0 inside and not a candidate, 1 candidate, 2 outside the image
@@ -716,40 +738,122 @@ __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__res
             }
             // key must be non-zero for candidates and equal exactly when the values are equal (values > INT_MIN)
             k = is_cand ? (v == 0 ? (int)0x80000000 : v) : 0;
-            key_out[fbase + (int64_t)r * W + c] = k;
-            bad[fbase + (int64_t)r * W + c] = touches ? 1 : 0;
+            if (is_cand) bad[fbase + (int64_t)r * W + c] = touches ? 1 : 0;
+            else if (markers) markers[fbase + (int64_t)r * W + c] = 0;
         }
         key[t] = k;
+        // a wave covers one 64-pixel tile row per trip: its ballot is the row's candidate bits, 64 consecutive bits of the
+        // flat array (they straddle two words unless the row starts on a word boundary; the array is zeroed by the caller)
+        const unsigned long long rowbits = __ballot(k != 0);
+        if (lane_id() == 0 && r < H && rowbits) {
+            const int64_t g = fbase + (int64_t)r * W + c0;
+            const int sh = (int)(g & 63);
+            atomicOr(cbits + (g >> 6), rowbits << sh);
+            if (sh) atomicOr(cbits + (g >> 6) + 1, rowbits >> (64 - sh));
+        }
     }
     if (__any(any_differs) && lane_id() == 0 && nonconst[ti.z] == 0) nonconst[ti.z] = 1;
     __syncthreads();
     ccl_tile_unions<true>(key, par);
-    ccl_tile_store(key, par, parent, fbase, r0, c0, H, W);
+    // tile-local roots -> frame-wide parent entries, candidates only
+    for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
+        const int r = r0 + i / CCL_TW, c = c0 + i % CCL_TW;
+        if (r >= H || c >= W || key[i] == 0) continue;
+        const int root = find_lds(par, i);
+        parent[fbase + (int64_t)r * W + c] = (r0 + root / CCL_TW) * W + c0 + root % CCL_TW;
+    }
 }
 
+// The passes after the border links walk the candidate bit words: one thread per 64-pixel word, most words are empty.
 // flatten the candidates' parents and move every pixel's own flag to its root
-__global__ void __launch_bounds__(256) locmax_propagate_kernel(int *__restrict__ parent, uint8_t *bad, int64_t n)
+__global__ void __launch_bounds__(256) locmax_propagate_kernel(int *__restrict__ parent, uint8_t *bad,
+                                                                const unsigned long long *__restrict__ cbits, int64_t n, int64_t total)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w * 64 >= total) return;
+    for (unsigned long long m = cbits[w]; m; m &= m - 1) {
+        const int64_t g = w * 64 + (__ffsll((long long)m) - 1);
+        const int64_t fbase = (g / n) * n;
+        const int i = (int)(g - fbase);
+        int *par = parent + fbase;
+        const int p = par[i];
+        int x = p, q;
+        while ((q = par[x]) != x) x = q;
+        if (x != p) par[i] = x;
+        if (x != i && bad[g]) bad[fbase + x] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256) locmax_out_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ bad,
+                                                          const int *__restrict__ nonconst, const unsigned long long *__restrict__ cbits,
+                                                          uint8_t *__restrict__ is_max, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t fbase = (int64_t)blockIdx.y * n;
-    int *par = parent + fbase;
-    int p = par[i];
-    if (p < 0) return;
-    int x = p, q;
-    while ((q = par[x]) != x) x = q;
-    if (x != p) par[i] = x;
-    if (x != (int)i && bad[fbase + i]) bad[fbase + x] = 1;
+    uint8_t v = 0;
+    if (cand_bit(cbits, fbase + i)) v = bad[fbase + parent[fbase + i]] == 0 && nonconst[blockIdx.y] != 0;
+    is_max[fbase + i] = v;
 }
 
-__global__ void __launch_bounds__(256) locmax_out_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ bad,
-                                                          const int *__restrict__ nonconst, uint8_t *__restrict__ is_max, int64_t n)
+// candidate nibble of the four pixels g0 .. g0 + 3 (the bit array ends in a spare zero word: word + 1 always exists)
+__device__ __forceinline__ unsigned cand_nibble(const unsigned long long *cbits, int64_t g0)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int64_t fbase = (int64_t)blockIdx.y * n;
-    int p = parent[fbase + i];
-    is_max[fbase + i] = (p >= 0 && bad[fbase + p] == 0 && nonconst[blockIdx.y] != 0);
+    const int sh = (int)(g0 & 63);
+    unsigned long long w = cbits[g0 >> 6] >> sh;
+    if (sh > 60) w |= cbits[(g0 >> 6) + 1] << (64 - sh);
+    return (unsigned)(w & 15ull);
+}
+
+// ccl_flatten_count_kernel / ccl_relabel_kernel for candidate components (parents already flat, see the propagate pass):
+// same blocks of SCAN_PIX pixels, same rank codes, but parent and label entries are only touched where a bit is set
+template <typename Pred>
+__global__ void __launch_bounds__(256) locmax_count_kernel(const int *__restrict__ parent, int *__restrict__ labels,
+                                                            int *__restrict__ blockcount, const unsigned long long *__restrict__ cbits,
+                                                            Pred pred, int64_t n, int nblk, int64_t total)
+{
+    const int b = blockIdx.y;
+    const int *par = parent + (int64_t)b * n;
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_PIX + threadIdx.x * 4;
+    int cnt = 0;
+    bool isroot[4] = {false, false, false, false};
+    if (i0 < n) {
+        const unsigned nib = cand_nibble(cbits, (int64_t)b * n + i0);
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = i0 + j;
+            if (!((nib >> j) & 1u) || i >= n) continue;
+            isroot[j] = par[i] == (int)i && pred((int64_t)b * n + i);
+            cnt += isroot[j];
+        }
+    }
+    int total_roots;
+    int rank = block_exclusive_scan(cnt, &total_roots);
+    for (int j = 0; j < 4; ++j)
+        if (isroot[j]) labels[(int64_t)b * n + i0 + j] = -(++rank);
+    if (threadIdx.x == 0) blockcount[b * nblk + blockIdx.x] = total_roots;
+}
+
+template <typename Pred>
+__global__ void __launch_bounds__(256) locmax_relabel_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
+                                                              const unsigned long long *__restrict__ cbits, Pred pred, int64_t n, int nblk,
+                                                              int64_t total)
+{
+    const int b = blockIdx.y;
+    const int *par = parent + (int64_t)b * n;
+    int *lab = labels + (int64_t)b * n;
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_PIX + threadIdx.x * 4;
+    if (i0 >= n) return;
+    const unsigned nib = cand_nibble(cbits, (int64_t)b * n + i0);
+    for (int j = 0; j < 4; ++j) {
+        if (!((nib >> j) & 1u) || i0 + j >= n) continue;
+        const int p = par[i0 + j];  // the component's root
+        int v = 0;
+        if (pred((int64_t)b * n + p)) {
+            v = __hip_atomic_load(lab + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // rank code or final label
+            if (v < 0) v = blockoff[b * nblk + p / SCAN_PIX] - v;
+        }
+        lab[i0 + j] = v;
+    }
 }
 
 // ---- overlap removal (C6) --------------------------------------------------
@@ -938,7 +1042,7 @@ size_t pcseg_local_maxima_workspace_bytes(int B, int H, int W)
 {
     if (!check_shape(B, H, W)) return 0;
     size_t n = (size_t)H * W;
-    return ccl_ws_bytes(B, H, W) + align_up(sizeof(int) * B * n) + align_up((size_t)B * n) + align_up(sizeof(int) * B);
+    return ccl_ws_bytes(B, H, W) + align_up(8 * (((size_t)B * n + 63) / 64 + 1)) + align_up((size_t)B * n) + align_up(sizeof(int) * B);
 }
 
 int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers, int32_t *counts, int B, int H, int W,
@@ -948,9 +1052,11 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
     PCSEG_REQUIRE(!markers || counts, "markers need counts");
     hipStream_t s = (hipStream_t)stream;
     int64_t n = (int64_t)H * W;
+    const int64_t total = (int64_t)B * n;
+    const size_t nwords = (size_t)((total + 63) / 64);
     Carver cv(workspace, workspace_bytes);
     CclWs ws = ccl_carve(cv, B, H, W);
-    int *key = cv.take<int>((size_t)B * n);
+    unsigned long long *cbits = cv.take<unsigned long long>(nwords + 1);
     uint8_t *bad = cv.take<uint8_t>((size_t)B * n);
     int *nonconst = cv.take<int>(B);
     if (!cv.ok()) {
@@ -958,21 +1064,34 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
         return PCSEG_ERR_WORKSPACE;
     }
     PCSEG_CHECK_HIP(hipMemsetAsync(nonconst, 0, sizeof(int) * B, s));
+    PCSEG_CHECK_HIP(hipMemsetAsync(cbits, 0, sizeof(unsigned long long) * (nwords + 1), s));  // one bit per pixel
     dim3 g2((W + LM_TW - 1) / LM_TW, (H + LM_TH - 1) / LM_TH, B);
-    PCSEG_LAUNCH(locmax_candidates_kernel, g2, dim3(256), 0, s, img, key, bad, nonconst, ws.parent, H, W);  // writes every slot of `bad`
+    PCSEG_LAUNCH(locmax_candidates_kernel, g2, dim3(256), 0, s, img, cbits, bad, nonconst, ws.parent, (int *)markers, H, W);
     PCSEG_CHECK_LAUNCH();
-    int rc = ccl_roots<KeyI32, true>(KeyI32{key, W, (int64_t)H * W}, ws.parent, B, H, W, s, true);  // tile pass: done above
+    // cross-tile links of the plateaus (tile pass: done above); keys come from the candidate bits and the image itself
+    int rc = ccl_roots<KeyCandBits, true>(KeyCandBits{img, cbits, W, n}, ws.parent, B, H, W, s, true);
     if (rc) return rc;
-    dim3 g1((unsigned)((n + 255) / 256), B);
-    PCSEG_LAUNCH(locmax_propagate_kernel, g1, dim3(256), 0, s, ws.parent, bad, n);
+    const dim3 gw((unsigned)((nwords + 255) / 256));
+    PCSEG_LAUNCH(locmax_propagate_kernel, gw, dim3(256), 0, s, ws.parent, bad, (const unsigned long long *)cbits, n, total);
     PCSEG_CHECK_LAUNCH();
     if (is_max) {
-        PCSEG_LAUNCH(locmax_out_kernel, g1, dim3(256), 0, s, ws.parent, bad, nonconst, is_max, n);
+        dim3 g1((unsigned)((n + 255) / 256), B);
+        PCSEG_LAUNCH(locmax_out_kernel, g1, dim3(256), 0, s, (const int *)ws.parent, (const uint8_t *)bad, (const int *)nonconst,
+                     (const unsigned long long *)cbits, is_max, n);
         PCSEG_CHECK_LAUNCH();
     }
     if (markers) {
-        rc = ccl_compact(ws.parent, ws.blockcount, ws.nblk, markers, counts, PredNotFlagged{bad, nonconst, n}, false, B, H, W, s);
-        if (rc) return rc;
+        // raster-order numbering of the accepted plateaus: count / scan / relabel over the candidate bits
+        const PredNotFlagged pred{bad, nonconst, n};
+        dim3 grid(ws.nblk, B);
+        PCSEG_LAUNCH((locmax_count_kernel<PredNotFlagged>), grid, dim3(256), 0, s, (const int *)ws.parent, markers, ws.blockcount,
+                     (const unsigned long long *)cbits, pred, n, ws.nblk, total);
+        PCSEG_CHECK_LAUNCH();
+        PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, ws.blockcount, counts, ws.nblk);
+        PCSEG_CHECK_LAUNCH();
+        PCSEG_LAUNCH((locmax_relabel_kernel<PredNotFlagged>), grid, dim3(256), 0, s, (const int *)ws.parent, markers,
+                     (const int *)ws.blockcount, (const unsigned long long *)cbits, pred, n, ws.nblk, total);
+        PCSEG_CHECK_LAUNCH();
     }
     return PCSEG_OK;
 }

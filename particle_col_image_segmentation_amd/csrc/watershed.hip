@@ -256,14 +256,17 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
     // the pure raster order).  At u == 0 the running value restarts from the halo cell in front of the row.
     unsigned *sLw = reinterpret_cast<unsigned *>(sLV);
     typedef unsigned u2v __attribute__((ext_vector_type(2)));
-    unsigned diff = 0;
+    // "did any lane lower a cell" is kept as a SCALAR lane mask: one v_cmp per step (its result lands in an SGPR pair, the
+    // OR into the running mask is a scalar instruction) instead of a per-lane xor + or -- five VALU operations per cell-step
+    // instead of six in a VALU-bound loop
+    unsigned long long diff = 0;
     {   // the first row takes the halo row's levels before the sweep (lane = column): lane 0 then needs no `up`
         constexpr int fr = DR > 0 ? 1 : WS_T, hr = DR > 0 ? 0 : WS_T + 1;
         const uint2 c = sLV[fr * P + 1 + lane];
         const unsigned h = sLV[hr * P + 1 + lane].x;
         const unsigned nw = min(c.x, max(c.y, h));
         atomicMin(&sLw[2 * (fr * P + 1 + lane)], nw);
-        diff |= nw ^ c.x;
+        diff |= __ballot(nw != c.x);
     }
     const int lr = DR > 0 ? lane + 1 : WS_T - lane;  // the lane's row (LDS coordinates 1 .. 64)
     const uint2 *row = sLV + lr * P;
@@ -299,7 +302,7 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
 #undef PCSEG_DS_READ
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
         unsigned wr[8];
-        unsigned batch_diff = 0;
+        unsigned long long batch_diff = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             // lane l takes lane l - 1's result of the previous step; lane 0 has no row above (wave_shr:1, `old` = +inf)
@@ -311,11 +314,11 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
             const unsigned m = min(up, lf);
             const unsigned cand = min(max(v, m), max(min(v, m), cur));  // median(value, m, cur) = min(cur, max(value, m))
             wr[k] = cand;
-            batch_diff |= cur ^ cand;
+            batch_diff |= __ballot(cur != cand);
             left = cand;
             prev = cand;
         }
-        if (__any(batch_diff != 0)) {
+        if (batch_diff != 0) {
             // (the level is the first word of the cell: the read's address and offset serve the atomic as they are)
 #define PCSEG_DS_MIN(k) asm volatile("ds_min_u32 %0, %1 offset:%2" : : "v"(ba[k]), "v"(wr[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
             PCSEG_DS_MIN(0) PCSEG_DS_MIN(1) PCSEG_DS_MIN(2) PCSEG_DS_MIN(3)
@@ -701,8 +704,8 @@ template <typename KeyT>
 __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM, const int b, const int tile_x, const int tile_y,
                                                  const KeyT *__restrict__ K,
                                                  const int *__restrict__ F, const uint8_t *__restrict__ active,
-                                                 int *__restrict__ parent, uint8_t *__restrict__ minmask, int H, int W, int tilesX,
-                                                 int tilesY)
+                                                 int *__restrict__ parent, uint8_t *__restrict__ minmask, uint8_t *__restrict__ bad,
+                                                 int H, int W, int tilesX, int tilesY)
 {
     const KeyT KINF = ~(KeyT)0;
     const int r0 = tile_y * UF_TH, c0 = tile_x * UF_TW;
@@ -754,7 +757,12 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
         }
         self[k] = v;
         sM[t] = m8;
-        if (r < H && c < W) minmask[fbase + (int64_t)r * W + c] = m8;
+        if (r < H && c < W) {
+            minmask[fbase + (int64_t)r * W + c] = m8;
+            // the "component cannot be resolved" marks of this level start clear: every root the label passes will look at
+            // lies in a tile this pass visits (instead of a memset of the whole array per level)
+            bad[fbase + (int64_t)r * W + c] = 0;
+        }
     }
     __syncthreads();
     // (2) row runs without atomics: a wave covers one 64-pixel tile row per trip; pixels joined by horizontal links form
@@ -816,18 +824,20 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
 template <typename KeyT, bool LIST>
 __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__ frame_list, const KeyT *__restrict__ K, const int *__restrict__ F,
                                                           const uint8_t *__restrict__ active, int *__restrict__ parent,
-                                                          uint8_t *__restrict__ minmask, int H, int W, int tilesX, int tilesY)
+                                                          uint8_t *__restrict__ minmask, uint8_t *__restrict__ bad, int H, int W,
+                                                          int tilesX, int tilesY)
 {
     __shared__ KeyT sK[UF_SH * UF_SW];
     __shared__ int par[UF_TH * UF_TW];
     __shared__ uint8_t sM[UF_LNS];
     if constexpr (!LIST) {
         const TileIndex t = xcd_tile_index();
-        ws_uf_tile_frame<KeyT>(sK, par, sM, t.z, t.x, t.y, K, F, active, parent, minmask, H, W, tilesX, tilesY);
+        ws_uf_tile_frame<KeyT>(sK, par, sM, t.z, t.x, t.y, K, F, active, parent, minmask, bad, H, W, tilesX, tilesY);
     } else {
         const int n = frame_list[-1];
         for (int gi = blockIdx.z; gi < n; gi += gridDim.z) {
-            ws_uf_tile_frame<KeyT>(sK, par, sM, frame_list[gi], blockIdx.x, blockIdx.y, K, F, active, parent, minmask, H, W, tilesX, tilesY);
+            ws_uf_tile_frame<KeyT>(sK, par, sM, frame_list[gi], blockIdx.x, blockIdx.y, K, F, active, parent, minmask, bad, H, W, tilesX,
+                                   tilesY);
             __syncthreads();  // the next listed frame reuses the tile arrays
         }
     }
@@ -1675,12 +1685,13 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             using KeyT = std::remove_const_t<std::remove_pointer_t<decltype(keys)>>;
             const int span = ws_frame_span(flist, B);  // frame dimension of the grids (see ws_for_frames)
             const dim3 ugrid(ugrid_full.x, ugrid_full.y, span), bgrid(bgrid_full.x, span), lgrid(lgrid_full.x, span);
+            uint8_t *level_bad = first_level ? uf_bad1 : uf_bad2;  // cleared by the tile pass, tile by tile
             if (flist)
                 PCSEG_LAUNCH((ws_uf_tile_kernel<KeyT, true>), ugrid, dim3(256), 0, s, flist, (const KeyT *)keys, (const int *)out, act,
-                             uf_parent, uf_mask, H, W, tilesX, tilesY);
+                             uf_parent, uf_mask, level_bad, H, W, tilesX, tilesY);
             else
                 PCSEG_LAUNCH((ws_uf_tile_kernel<KeyT, false>), ugrid, dim3(256), 0, s, flist, (const KeyT *)keys, (const int *)out, act,
-                             uf_parent, uf_mask, H, W, tilesX, tilesY);
+                             uf_parent, uf_mask, level_bad, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
             if (border_px > 0) {
                 PCSEG_LAUNCH(ws_uf_border_kernel, bgrid, dim3(256), 0, s, flist, (const uint8_t *)uf_mask, act, uf_parent, H, W,
@@ -1709,7 +1720,6 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         uint8_t *active = dirtyB;  // both mark buffers are empty again after a fixed point: free between the two loops
         PCSEG_CHECK_HIP(hipMemsetAsync(active, 0, ntiles_max, s));
         PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, ntiles_max, s));
-        PCSEG_CHECK_HIP(hipMemsetAsync(uf_bad1, 0, n, s));
         int rc = assign_labels((const unsigned *)L, (const int *)nullptr, (const uint8_t *)nullptr, flags, true);
         if (rc) return rc;
         if (verify) {
@@ -1729,7 +1739,6 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             PCSEG_LAUNCH(ws_uf_label_kernel<UF_REPAIR>, lgrid, dim3(256), 0, s, (const int *)frame_list, (const int *)uf_parent, out,
                          (const uint8_t *)nullptr, uf_bad1, markers, mask, flags, active, npx, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            PCSEG_CHECK_HIP(hipMemsetAsync(uf_bad2, 0, n, s));
             if (verify) {
                 // whole flagged frames, so that the explicit per-pixel check of the second level sees valid keys everywhere
                 PCSEG_LAUNCH(ws_activate_frames_kernel, lgrid, dim3(256), 0, s, (const int *)frame_list, (const int *)flags, active,

@@ -423,15 +423,17 @@ def classify_regions(stats, cls_out, counts, tables):
     counts = _req(counts, torch.int32, 1)
     B, cap = stats.shape[0], stats.shape[1]
     dev = stats.device
+    # no fills: the kernel writes kind / slot_of / cells for every region below counts[b], the lists up to their lengths and
+    # every per-frame scalar; nothing reads beyond those (eight fill launches per batch, 26 MB of them, for nothing)
     out = {
-        "kind": torch.zeros((B, cap), dtype=torch.uint8, device=dev),
-        "slot_of": torch.full((B, cap), 255, dtype=torch.uint8, device=dev),
-        "cells": torch.zeros((B, cap), dtype=torch.int32, device=dev),
-        "particle_area": torch.zeros((B,), dtype=torch.int64, device=dev),
-        "type_stats": torch.zeros((B, 4, 4), dtype=torch.int64, device=dev),
-        "region_list": torch.full((B, 5, cap), -1, dtype=torch.int32, device=dev),
-        "n_list": torch.zeros((B, 5), dtype=torch.int32, device=dev),
-        "nan_flag": torch.zeros((B,), dtype=torch.int32, device=dev),
+        "kind": torch.empty((B, cap), dtype=torch.uint8, device=dev),
+        "slot_of": torch.empty((B, cap), dtype=torch.uint8, device=dev),
+        "cells": torch.empty((B, cap), dtype=torch.int32, device=dev),
+        "particle_area": torch.empty((B,), dtype=torch.int64, device=dev),
+        "type_stats": torch.empty((B, 4, 4), dtype=torch.int64, device=dev),
+        "region_list": torch.empty((B, 5, cap), dtype=torch.int32, device=dev),
+        "n_list": torch.empty((B, 5), dtype=torch.int32, device=dev),
+        "nan_flag": torch.empty((B,), dtype=torch.int32, device=dev),
     }
     lib = _lib.load()
     hp = lambda a: ctypes.c_void_p(a.ctypes.data)
