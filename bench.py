@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel event table to stderr")
     ap.add_argument("--lanes", type=int, default=0,
                     help="batches in flight (0 = the pipeline's default: 2 graph replays, or 8 host threads with --eager)")
+    ap.add_argument("--no-merge", action="store_true",
+                    help="A/B aid, NOT the headline workload: skip the proximity merges (what do their kernels cost the batch?)")
     ap.add_argument("--eager", action="store_true",
                     help="A/B aid: launch every kernel from host threads (round 2's mode) instead of replaying hipGraphs")
     ap.add_argument("--batch64-frames", type=int, default=64,
@@ -308,7 +310,7 @@ def _run(args):
         stack[:, 3] = torch.round(stack[:, 3] * args.levels) / args.levels
     graph = not args.eager
     pipe = FramePipeline(ct, overlap=not args.serial, lanes=args.lanes or None, multi_stream=not args.single_class_stream,
-                         graph=graph)
+                         graph=graph, merged=not args.no_merge)
     res = None
     # setup (not warmup): in graph mode the first pass through each lane captures its graph (one plain run + the capture);
     # in eager mode two priming passes fill torch's caching allocator with every workspace block.  Then W untimed warmup
@@ -431,7 +433,8 @@ def _run(args):
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 planes / u8 class maps / int32 labels / f64 ROI sums", "data": "synthetic",
-            "config": {"workload": ("BASELINE config 2" if not args.levels else "boundary plane quantised to k/%d" % args.levels)
+            "config": {"workload": ("BASELINE config 2" if not (args.levels or args.no_merge) else
+                                    "NOT THE HEADLINE (levels=%d, merges %s)" % (args.levels, "off" if args.no_merge else "on"))
                                    + ": batch of %d frames %dx%dx5 float32 per GPU, full kernel chain, "
                                    "inputs resident in HBM" % (B, H, W),
                        "frames_per_gpu": B, "height": H, "width": W, "planes": 5, "parallelism": "frames x%d" % world,

@@ -796,63 +796,66 @@ __global__ void __launch_bounds__(256) locmax_out_kernel(const int *__restrict__
     is_max[fbase + i] = v;
 }
 
-// candidate nibble of the four pixels g0 .. g0 + 3 (the bit array ends in a spare zero word: word + 1 always exists)
-__device__ __forceinline__ unsigned cand_nibble(const unsigned long long *cbits, int64_t g0)
+// the 64 candidate bits of pixels i0 .. i0 + 63 of frame b (bits of pixels >= n cleared; the bit array ends in a spare
+// zero word, so word + 1 always exists)
+__device__ __forceinline__ unsigned long long cand_word(const unsigned long long *cbits, int b, int64_t i0, int64_t n)
 {
+    if (i0 >= n) return 0ull;
+    const int64_t g0 = (int64_t)b * n + i0;
     const int sh = (int)(g0 & 63);
     unsigned long long w = cbits[g0 >> 6] >> sh;
-    if (sh > 60) w |= cbits[(g0 >> 6) + 1] << (64 - sh);
-    return (unsigned)(w & 15ull);
+    if (sh) w |= cbits[(g0 >> 6) + 1] << (64 - sh);
+    if (n - i0 < 64) w &= (1ull << (n - i0)) - 1ull;
+    return w;
 }
 
 // ccl_flatten_count_kernel / ccl_relabel_kernel for candidate components (parents already flat, see the propagate pass):
-// same blocks of SCAN_PIX pixels, same rank codes, but parent and label entries are only touched where a bit is set
+// same SCAN_PIX blocks, same rank codes, but one THREAD per 64-pixel word of candidate bits (most are empty) instead of
+// one per four pixels: sixteen consecutive lanes are one SCAN_PIX block, their root counts are ranked by a 16-wide scan.
+static_assert(SCAN_PIX == 1024, "sixteen 64-bit words per count block");
 template <typename Pred>
 __global__ void __launch_bounds__(256) locmax_count_kernel(const int *__restrict__ parent, int *__restrict__ labels,
                                                             int *__restrict__ blockcount, const unsigned long long *__restrict__ cbits,
-                                                            Pred pred, int64_t n, int nblk, int64_t total)
+                                                            Pred pred, int64_t n, int nblk)
 {
     const int b = blockIdx.y;
     const int *par = parent + (int64_t)b * n;
-    const int64_t i0 = (int64_t)blockIdx.x * SCAN_PIX + threadIdx.x * 4;
-    int cnt = 0;
-    bool isroot[4] = {false, false, false, false};
-    if (i0 < n) {
-        const unsigned nib = cand_nibble(cbits, (int64_t)b * n + i0);
-        for (int j = 0; j < 4; ++j) {
-            const int64_t i = i0 + j;
-            if (!((nib >> j) & 1u) || i >= n) continue;
-            isroot[j] = par[i] == (int)i && pred((int64_t)b * n + i);
-            cnt += isroot[j];
-        }
+    const int64_t word = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i0 = word * 64;
+    unsigned long long roots = 0;
+    for (unsigned long long m = cand_word(cbits, b, i0, n); m; m &= m - 1) {
+        const int j = __ffsll((long long)m) - 1;
+        const int64_t i = i0 + j;
+        if (par[i] == (int)i && pred((int64_t)b * n + i)) roots |= 1ull << j;
     }
-    int total_roots;
-    int rank = block_exclusive_scan(cnt, &total_roots);
-    for (int j = 0; j < 4; ++j)
-        if (isroot[j]) labels[(int64_t)b * n + i0 + j] = -(++rank);
-    if (threadIdx.x == 0) blockcount[b * nblk + blockIdx.x] = total_roots;
+    const int cnt = __popcll(roots);
+    int inc = cnt;
+    for (int off = 1; off < 16; off <<= 1) {
+        const int t = __shfl_up(inc, off, 16);
+        if ((threadIdx.x & 15) >= off) inc += t;
+    }
+    int rank = inc - cnt;
+    for (unsigned long long m = roots; m; m &= m - 1) labels[(int64_t)b * n + i0 + (__ffsll((long long)m) - 1)] = -(++rank);
+    if ((threadIdx.x & 15) == 15 && word / 16 < nblk) blockcount[b * nblk + (int)(word / 16)] = inc;
 }
 
 template <typename Pred>
 __global__ void __launch_bounds__(256) locmax_relabel_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
-                                                              const unsigned long long *__restrict__ cbits, Pred pred, int64_t n, int nblk,
-                                                              int64_t total)
+                                                              const unsigned long long *__restrict__ cbits, Pred pred, int64_t n, int nblk)
 {
     const int b = blockIdx.y;
     const int *par = parent + (int64_t)b * n;
     int *lab = labels + (int64_t)b * n;
-    const int64_t i0 = (int64_t)blockIdx.x * SCAN_PIX + threadIdx.x * 4;
-    if (i0 >= n) return;
-    const unsigned nib = cand_nibble(cbits, (int64_t)b * n + i0);
-    for (int j = 0; j < 4; ++j) {
-        if (!((nib >> j) & 1u) || i0 + j >= n) continue;
-        const int p = par[i0 + j];  // the component's root
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 64;
+    for (unsigned long long m = cand_word(cbits, b, i0, n); m; m &= m - 1) {
+        const int64_t i = i0 + (__ffsll((long long)m) - 1);
+        const int p = par[i];  // the component's root
         int v = 0;
         if (pred((int64_t)b * n + p)) {
             v = __hip_atomic_load(lab + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // rank code or final label
             if (v < 0) v = blockoff[b * nblk + p / SCAN_PIX] - v;
         }
-        lab[i0 + j] = v;
+        lab[i] = v;
     }
 }
 
@@ -1083,14 +1086,14 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
     if (markers) {
         // raster-order numbering of the accepted plateaus: count / scan / relabel over the candidate bits
         const PredNotFlagged pred{bad, nonconst, n};
-        dim3 grid(ws.nblk, B);
+        dim3 grid((unsigned)((ws.nblk + 15) / 16), B);  // a thread per 64-pixel word, sixteen words per count block
         PCSEG_LAUNCH((locmax_count_kernel<PredNotFlagged>), grid, dim3(256), 0, s, (const int *)ws.parent, markers, ws.blockcount,
-                     (const unsigned long long *)cbits, pred, n, ws.nblk, total);
+                     (const unsigned long long *)cbits, pred, n, ws.nblk);
         PCSEG_CHECK_LAUNCH();
         PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, ws.blockcount, counts, ws.nblk);
         PCSEG_CHECK_LAUNCH();
         PCSEG_LAUNCH((locmax_relabel_kernel<PredNotFlagged>), grid, dim3(256), 0, s, (const int *)ws.parent, markers,
-                     (const int *)ws.blockcount, (const unsigned long long *)cbits, pred, n, ws.nblk, total);
+                     (const int *)ws.blockcount, (const unsigned long long *)cbits, pred, n, ws.nblk);
         PCSEG_CHECK_LAUNCH();
     }
     return PCSEG_OK;

@@ -360,6 +360,139 @@ __global__ void __launch_bounds__(256, PCSEG_RED_WAVES) region_reduce_col_kernel
     }
 }
 
+// ---- plane sums of TWO label images in one pass over the planes (M1 for the class-map components and for the refined
+// ROIs: both tables report isotope sums, both label images are final by the end of a batch's chains, and the planes are
+// by far the largest thing either reduction reads).  Same column-run scheme as region_reduce_col_kernel -- a lane owns 4
+// adjacent columns, walks down COL_ROWS rows and keeps each vertical run's float64 sums in registers -- but only the
+// sums: the integer columns (area, centroid sums, bounding box, first pixel) come from the plane-free kernel, which
+// reads 4 bytes per pixel.  Image A is restricted to the classes in `sel` (bit v = class value v; 0 = every pixel).
+struct SumSlots {
+    int *tags;
+    double (*lsum)[RED_MAXC];
+};
+
+template <int NC>
+__device__ __forceinline__ void sums_commit(const SumSlots &ls, double *gsum, int cap, int C, int l, const double *acc)
+{
+    if (l <= 0 || l > cap) return;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) any = any || acc[k] != 0.0;
+    if (!any) return;  // (regions outside the class selection, runs of zero-valued planes)
+    const int slot = l & (RED_SLOTS - 1);
+    const int tag = atomicCAS(&ls.tags[slot], 0, l);
+    if (tag == 0 || tag == l) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+            if (k < C && acc[k] != 0.0) atomicAdd(&ls.lsum[slot][k], acc[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+            if (k < C && acc[k] != 0.0) atomicAdd(&gsum[(int64_t)(l - 1) * C + k], acc[k]);
+    }
+}
+
+template <int NC>
+__global__ void __launch_bounds__(256, 2) region_sums2_col_kernel(const int *__restrict__ labels_a, const uint8_t *__restrict__ cls,
+                                                                  unsigned long long sel, const int *__restrict__ labels_b,
+                                                                  const float *__restrict__ planes, int C, int H, int W, int cap_a,
+                                                                  int cap_b, double *__restrict__ sums_a, double *__restrict__ sums_b)
+{
+    __shared__ int tags_a[RED_SLOTS], tags_b[RED_SLOTS];
+    __shared__ double lsum_a[RED_SLOTS][RED_MAXC], lsum_b[RED_SLOTS][RED_MAXC];
+    const int b = blockIdx.z;
+    const int64_t n = (int64_t)H * W;
+    const int *la = labels_a + (int64_t)b * n, *lb = labels_b + (int64_t)b * n;
+    const float *pl = planes + (int64_t)b * C * n;
+    double *ga = sums_a + (int64_t)b * cap_a * C, *gb = sums_b + (int64_t)b * cap_b * C;
+    for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
+        tags_a[i] = 0;
+        tags_b[i] = 0;
+        for (int k = 0; k < RED_MAXC; ++k) { lsum_a[i][k] = 0.0; lsum_b[i][k] = 0.0; }
+    }
+    __syncthreads();
+    const SumSlots sa{tags_a, lsum_a}, sb{tags_b, lsum_b};
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int r0 = blockIdx.y * COL_ROWS, r1 = min(H, r0 + COL_ROWS);
+    if (c < W) {
+        int cur_a[4] = {0, 0, 0, 0}, cur_b[4] = {0, 0, 0, 0};
+        double acc_a[4][NC], acc_b[4][NC];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < NC; ++k) { acc_a[j][k] = 0.0; acc_b[j][k] = 0.0; }
+        // the next row's eight 16-byte loads are issued before this row is processed
+        int4 a4n = make_int4(0, 0, 0, 0), b4n = make_int4(0, 0, 0, 0);
+        float4 vn[NC];
+        unsigned wantn = 0xF;
+        auto fetch = [&](int r) {
+            a4n = make_int4(0, 0, 0, 0);
+            b4n = make_int4(0, 0, 0, 0);
+            if (r < r1) {
+                a4n = *reinterpret_cast<const int4 *>(la + (int64_t)r * W + c);
+                b4n = *reinterpret_cast<const int4 *>(lb + (int64_t)r * W + c);
+                if (sel) {
+                    const unsigned cw = *reinterpret_cast<const unsigned *>(cls + (int64_t)b * n + (int64_t)r * W + c);
+                    wantn = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned cv = (cw >> (8 * j)) & 255u;
+                        if (cv < 64 && ((sel >> cv) & 1ull)) wantn |= 1u << j;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NC; ++k)
+                    vn[k] = k < C ? *reinterpret_cast<const float4 *>(pl + (int64_t)k * n + (int64_t)r * W + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        fetch(r0);
+        for (int r = r0; r <= r1; ++r) {
+            const int4 a4 = a4n, b4 = b4n;
+            const unsigned want = wantn;
+            float4 v[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) v[k] = vn[k];
+            fetch(r + 1);
+            const int aa[4] = {a4.x, a4.y, a4.z, a4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};  // (row r1: zeros -> every run ends)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (aa[j] != cur_a[j]) {
+                    sums_commit<NC>(sa, ga, cap_a, C, cur_a[j], acc_a[j]);
+                    cur_a[j] = aa[j];
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) acc_a[j][k] = 0.0;
+                }
+                if (bb[j] != cur_b[j]) {
+                    sums_commit<NC>(sb, gb, cap_b, C, cur_b[j], acc_b[j]);
+                    cur_b[j] = bb[j];
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) acc_b[j][k] = 0.0;
+                }
+                if (r < r1) {
+                    const bool in_a = aa[j] > 0 && ((want >> j) & 1u), in_b = bb[j] > 0;
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) {
+                        const float4 f = v[k];
+                        const double x = (double)(j == 0 ? f.x : (j == 1 ? f.y : (j == 2 ? f.z : f.w)));
+                        if (in_a) acc_a[j][k] += x;
+                        if (in_b) acc_b[j][k] += x;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
+        const int l1 = tags_a[i], l2 = tags_b[i];
+        if (l1)
+            for (int k = 0; k < C; ++k)
+                if (lsum_a[i][k] != 0.0) atomicAdd(&ga[(int64_t)(l1 - 1) * C + k], lsum_a[i][k]);
+        if (l2)
+            for (int k = 0; k < C; ++k)
+                if (lsum_b[i][k] != 0.0) atomicAdd(&gb[(int64_t)(l2 - 1) * C + k], lsum_b[i][k]);
+    }
+}
+
 __global__ void __launch_bounds__(256) region_class_kernel(const long long *__restrict__ stats, const uint8_t *__restrict__ cls,
                                                             const int *__restrict__ counts, uint8_t *__restrict__ cls_out,
                                                             int cap, int64_t n)
@@ -827,7 +960,7 @@ int pcseg_region_reduce_sel(const int32_t *labels, const int32_t *counts, const 
     PCSEG_REQUIRE(labels && stats && cap >= 1 && check_shape(B, H, W), "bad arguments");
     PCSEG_REQUIRE(sum_class_bits == 0 || (cls && planes), "a class selection needs the class map and planes");
     const unsigned long long sel = sum_class_bits;
-    PCSEG_REQUIRE((!planes && !sums) || (planes && sums && C >= 1 && C <= RED_MAXC), "planes/sums/C mismatch (C <= 8)");
+    PCSEG_REQUIRE((!planes && !sums) || (sums && C >= 1 && C <= RED_MAXC), "planes/sums/C mismatch (C <= 8)");
     PCSEG_REQUIRE(!cls || cls_out, "cls needs cls_out");
     hipStream_t s = (hipStream_t)stream;
     if (overflow) PCSEG_CHECK_HIP(hipMemsetAsync(overflow, 0, sizeof(int32_t) * B, s));
@@ -866,6 +999,29 @@ int pcseg_region_reduce(const int32_t *labels, const uint8_t *cls, const float *
                         int64_t *stats, uint8_t *cls_out, double *sums, int32_t *overflow, pcseg_stream_t stream)
 {
     return pcseg_region_reduce_n(labels, nullptr, cls, planes, C, B, H, W, cap, stats, cls_out, sums, overflow, stream);
+}
+
+int pcseg_region_sums2(const int32_t *labels_a, const uint8_t *cls, uint64_t sum_class_bits, int cap_a, double *sums_a,
+                       const int32_t *labels_b, int cap_b, double *sums_b, const float *planes, int C, int B, int H, int W,
+                       pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(labels_a && labels_b && sums_a && sums_b && planes && cap_a >= 1 && cap_b >= 1 && C >= 1 && C <= RED_MAXC &&
+                      check_shape(B, H, W),
+                  "bad arguments (C <= 8)");
+    PCSEG_REQUIRE(sum_class_bits == 0 || cls, "a class selection needs the class map");
+    PCSEG_REQUIRE((W % 4) == 0 && (((uintptr_t)labels_a | (uintptr_t)labels_b | (uintptr_t)planes) % 16) == 0 &&
+                      (!sum_class_bits || ((uintptr_t)cls % 4) == 0),
+                  "W must be a multiple of 4 and the images 16-byte aligned (use pcseg_region_reduce_sel per image otherwise)");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 cgrid((W / 4 + 255) / 256, (H + COL_ROWS - 1) / COL_ROWS, B);
+    if (C <= 5)
+        PCSEG_LAUNCH(region_sums2_col_kernel<5>, cgrid, dim3(256), 0, s, labels_a, cls, (unsigned long long)sum_class_bits, labels_b, planes, C,
+                     H, W, cap_a, cap_b, sums_a, sums_b);
+    else
+        PCSEG_LAUNCH(region_sums2_col_kernel<8>, cgrid, dim3(256), 0, s, labels_a, cls, (unsigned long long)sum_class_bits, labels_b, planes, C,
+                     H, W, cap_a, cap_b, sums_a, sums_b);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
 }
 
 size_t pcseg_merge_groups_workspace_bytes(int B, int list_cap)

@@ -302,6 +302,7 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
 #undef PCSEG_DS_READ
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
         unsigned wr[8];
+        bool lowered[8];  // per lane "this step lowered its cell": lives as a lane mask in an SGPR pair (the v_cmp's result)
         unsigned long long batch_diff = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -314,13 +315,18 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
             const unsigned m = min(up, lf);
             const unsigned cand = min(max(v, m), max(min(v, m), cur));  // median(value, m, cur) = min(cur, max(value, m))
             wr[k] = cand;
-            batch_diff |= __ballot(cur != cand);
+            lowered[k] = cur != cand;
+            batch_diff |= __ballot(lowered[k]);
             left = cand;
             prev = cand;
         }
         if (batch_diff != 0) {
-            // (the level is the first word of the cell: the read's address and offset serve the atomic as they are)
-#define PCSEG_DS_MIN(k) asm volatile("ds_min_u32 %0, %1 offset:%2" : : "v"(ba[k]), "v"(wr[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
+            // Only the lanes that lowered their cell go to the LDS (the compare is the one above: its lane mask becomes the
+            // exec mask of the atomic) -- late iterations lower a handful of cells, and the LDS array, not the VALU, is what
+            // the four waves of a tile queue for.  Still an atomic min: another wave may have lowered the cell since the
+            // batch was read.  (The level is the first word of the cell: the read's address and offset serve as they are.)
+#define PCSEG_DS_MIN(k)                                                                                                             \
+            if (lowered[k]) asm volatile("ds_min_u32 %0, %1 offset:%2" : : "v"(ba[k]), "v"(wr[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
             PCSEG_DS_MIN(0) PCSEG_DS_MIN(1) PCSEG_DS_MIN(2) PCSEG_DS_MIN(3)
             PCSEG_DS_MIN(4) PCSEG_DS_MIN(5) PCSEG_DS_MIN(6) PCSEG_DS_MIN(7)
 #undef PCSEG_DS_MIN

@@ -113,9 +113,29 @@ def compact_labels(roots):
     return labels, counts
 
 
-def region_reduce(labels, counts=None, cls=None, planes=None, cap=None, sum_classes=0):
+def region_sums2(labels_a, cls, sum_classes, sums_a, labels_b, sums_b, planes):
+    """Per-label plane sums of two label images in ONE pass over the planes (csrc/reduce.hip region_sums2_col_kernel):
+    ``sums_a`` / ``sums_b`` (float64 (B, cap, C), zeroed by ``region_reduce(..., zero_sums=C)``) are added to in place;
+    image A only under the class values in ``sum_classes`` (bit v = value v, 0 = everywhere)."""
+    labels_a = _req(labels_a, torch.int32, 3)
+    labels_b = _req(labels_b, torch.int32, 3)
+    planes = _req(planes, torch.float32, 4)
+    sums_a = _req(sums_a, torch.float64, 3)
+    sums_b = _req(sums_b, torch.float64, 3)
+    cls = _req(cls, torch.uint8, 3) if cls is not None else None
+    B, C, H, W = planes.shape
+    if tuple(labels_a.shape) != (B, H, W) or tuple(labels_b.shape) != (B, H, W) or sums_a.shape[2] != C or sums_b.shape[2] != C:
+        raise ValueError("label images / sums tables do not match the planes")
+    lib = _lib.load()
+    _lib.check(lib.pcseg_region_sums2(_ptr(labels_a), _ptr(cls), int(sum_classes), sums_a.shape[1], _ptr(sums_a), _ptr(labels_b),
+                                      sums_b.shape[1], _ptr(sums_b), _ptr(planes), C, B, H, W, _stream()), "region_sums2")
+
+
+def region_reduce(labels, counts=None, cls=None, planes=None, cap=None, sum_classes=0, zero_sums=0):
     """regionprops sums + optional class at first pixel + optional per-label plane sums.  ``sum_classes`` (bit v = class
     value v; 0 = all): plane sums only over pixels of those classes -- the other regions keep 0 and cost no plane reads.
+    ``zero_sums`` = C (without ``planes``): also return a (B, cap, C) sums table with the rows below ``counts`` zeroed, for
+    :func:`region_sums2`.
 
     Returns (stats int64 (B,cap,8), cls_out uint8 (B,cap) | None, sums float64 (B,cap,C) | None,
     overflow int32 (B,))."""
@@ -138,6 +158,9 @@ def region_reduce(labels, counts=None, cls=None, planes=None, cap=None, sum_clas
     if planes is not None:
         planes = _req(planes, torch.float32, 4)
         C = planes.shape[1]
+        sums = torch.empty((B, cap, C), dtype=torch.float64, device=dev)
+    elif zero_sums:
+        C = int(zero_sums)
         sums = torch.empty((B, cap, C), dtype=torch.float64, device=dev)
     if counts is not None:
         counts = _req(counts, torch.int32, 1)

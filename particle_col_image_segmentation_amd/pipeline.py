@@ -232,6 +232,7 @@ class FramePipeline:
                 self._merge_stage(stack, res, s)
             self._fill_stage(stack, res)
             self._refine_chain(stack, res)
+            self._sums_stage(stack, res)
             return res
         # The chain is a small graph, not a line: the class-map stage (front end, region table, classification), the
         # merge of each cell type and of all types together (they only need the classification), the particle fill (it
@@ -305,6 +306,7 @@ class FramePipeline:
                 self._merge_stage(stack, out, sl)
             self._fill_stage(stack, out)
             self._refine_chain(stack, out)
+            self._sums_stage(stack, out)
             return dict(out)
 
         slot.stream.wait_stream(torch.cuda.current_stream(dev))
@@ -341,6 +343,11 @@ class FramePipeline:
             self._class_stage(stack, out, denoised_ready=(ev_z := torch.cuda.Event()))
             ev_c = torch.cuda.Event()
             ev_c.record(s_class)
+        with torch.cuda.stream(s_refine):
+            # the isotope sums of BOTH label images in one pass over the planes, once both are final
+            s_refine.wait_event(ev_c)
+            _on(s_refine, out["labels"], out["denoised"], out["cc_sums"])
+            self._sums_stage(stack, out)
         with torch.cuda.stream(s_fill):
             if s_fill is not s_class:
                 s_fill.wait_event(ev_z)
@@ -371,12 +378,9 @@ class FramePipeline:
         res["denoised"] = z
         if denoised_ready is not None:
             denoised_ready.record(torch.cuda.current_stream())
-        # ---- region table (+ isotope sums of the class components) (A3, M1)
-        # isotope sums are only ever reported for cell / cluster regions: the planes are read under those classes only
-        cell_bits = 0
-        for v in tb.cell_values:
-            cell_bits |= 1 << int(v)
-        stats, cls_out, cc_sums, overflow = ops.region_reduce(labels, counts, cls=z, planes=stack, cap=cap, sum_classes=cell_bits)
+        # ---- region table (A3): the integer columns only (4 bytes per pixel); the isotope sums of the class components
+        # come from the fused plane pass at the end of the batch (_sums_stage), into the zeroed table made here
+        stats, cls_out, cc_sums, overflow = ops.region_reduce(labels, counts, cls=z, cap=cap, zero_sums=C)
         res.update(labels=labels, counts=counts, stats=stats, cls_out=cls_out, cc_sums=cc_sums, overflow=overflow)
         # ---- classification, cluster cell counts, region lists (A3 tail, A4)
         res.update(ops.classify_regions(stats, cls_out, counts, tb))
@@ -422,9 +426,27 @@ class FramePipeline:
         _, markers, n_markers = ops.local_maxima(d2, want_mask=False)
         ws_labels, tie_flags = ops.watershed(bm, markers, mask, mode=self.watershed_mode)
         res.update(mask=mask, markers=markers, n_markers=n_markers, ws_labels=ws_labels, tie_flags=tie_flags)
-        # ---- isotope sums of the refined ROIs (M1)
-        ws_stats, _, ws_sums, ws_overflow = ops.region_reduce(ws_labels, n_markers, planes=stack, cap=cap)
+        # ---- area / centroid sums of the refined ROIs; their isotope sums: _sums_stage
+        ws_stats, _, ws_sums, ws_overflow = ops.region_reduce(ws_labels, n_markers, cap=cap, zero_sums=C)
         res.update(ws_stats=ws_stats, ws_sums=ws_sums, ws_overflow=ws_overflow)
+
+    def _sums_stage(self, stack, res):
+        """per-ROI isotope sums (M1, .m:122-135) of the class-map components AND of the refined ROIs in one pass over
+        the planes.  Sums of class components are only ever reported for cell / cluster regions (tiff_analysis.py:1041-1044):
+        that image is summed under the cell classes only."""
+        cell_bits = 0
+        for v in self.tables_.cell_values:
+            cell_bits |= 1 << int(v)
+        B, C, H, W = stack.shape
+        if W % 4 == 0:
+            ops.region_sums2(res["labels"], res["denoised"], cell_bits, res["cc_sums"], res["ws_labels"], res["ws_sums"], stack)
+            return
+        # ragged widths: the per-image kernels (their plane pass adds nothing to the already counted integer columns'
+        # cost worth a special path)
+        cap = res["stats"].shape[1]
+        _, _, res["cc_sums"], _ = ops.region_reduce(res["labels"], res["counts"], cls=res["denoised"], planes=stack, cap=cap,
+                                                    sum_classes=cell_bits)
+        _, _, res["ws_sums"], _ = ops.region_reduce(res["ws_labels"], res["n_markers"], planes=stack, cap=cap)
 
     # ------------------------------------------------------------------ table output
     def table_columns(self, C, ratios=RATIOS_5):

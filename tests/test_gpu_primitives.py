@@ -129,6 +129,33 @@ def test_region_reduce(ops):
     np.testing.assert_array_equal(host(stats)[0], orc.region_table(labs[0])[:5])
 
 
+def test_region_sums2(ops):
+    """The fused plane pass: per-label float64 sums of two label images (class components under a class selection, and a
+    second, unrestricted labelling) in one read of the planes, against the oracle's per-image sums."""
+    from particle_col_image_segmentation_amd import synth
+    for (b, h, w) in [(2, 64, 64), (2, 200, 332), (1, 512, 512), (3, 33, 68)]:
+        st = synth.gen_batch(40, b, h, w)
+        cm = np.stack([orc.median_filter(c) for c in synth.class_map_from_stack(st)])
+        la = np.stack([orc.label(c) for c in cm])
+        lb = np.stack([orc.label(RNG.random((h, w)) < 0.55) for _ in range(b)])
+        ca = torch.tensor([int(l.max()) for l in la], dtype=torch.int32).cuda()
+        cb = torch.tensor([int(l.max()) for l in lb], dtype=torch.int32).cuda()
+        sel = (1 << 1) | (1 << 2)
+        stats_a, _, sums_a, _ = ops.region_reduce(dev(la), ca, dev(cm), zero_sums=5)
+        stats_b, _, sums_b, _ = ops.region_reduce(dev(lb), cb, zero_sums=5)
+        ops.region_sums2(dev(la), dev(cm), sel, sums_a, dev(lb), sums_b, dev(st))
+        for i in range(b):
+            na, nb = int(la[i].max()), int(lb[i].max())
+            np.testing.assert_array_equal(host(stats_a)[i, :na], orc.region_table(la[i]))
+            np.testing.assert_array_equal(host(stats_b)[i, :nb], orc.region_table(lb[i]))
+            first = orc.region_table(la[i])[:, 7]
+            is_sel = np.isin(cm[i].ravel()[first], [1, 2])
+            exp_a = orc.channel_sums(la[i], st[i])
+            np.testing.assert_allclose(host(sums_a)[i, :na][is_sel], exp_a[is_sel], rtol=1e-12, atol=0)
+            assert not host(sums_a)[i, :na][~is_sel].any()
+            np.testing.assert_allclose(host(sums_b)[i, :nb], orc.channel_sums(lb[i], st[i]), rtol=1e-12, atol=0)
+
+
 def test_edt(ops, primitives):
     for c in golden_cases(primitives, "edt"):
         d2 = host(ops.edt_sq(one(c["inp"])))[0]
