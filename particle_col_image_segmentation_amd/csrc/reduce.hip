@@ -212,8 +212,10 @@ constexpr int COL_ROWS = PCSEG_COL_ROWS;
 #ifndef PCSEG_RED_WAVES
 #define PCSEG_RED_WAVES 2
 #endif
+// (the plane-free instantiation keeps no float64 accumulators: eight blocks per CU instead of two -- it is a latency-bound
+// stream of 4 bytes per pixel)
 template <int NC>
-__global__ void __launch_bounds__(256, PCSEG_RED_WAVES) region_reduce_col_kernel(const int *__restrict__ labels, const float *__restrict__ planes,
+__global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 8) region_reduce_col_kernel(const int *__restrict__ labels, const float *__restrict__ planes,
                                                                  const uint8_t *__restrict__ cls, unsigned long long sel, int C,
                                                                  int H, int W, int cap, long long *__restrict__ stats,
                                                                  double *__restrict__ sums, int *__restrict__ overflow)

@@ -133,6 +133,12 @@ __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__res
 // 16-wave barriers, the shifted tiling has 81 tiles per 1024^2 frame instead of 64 (+27 %) where 64-tiles have 289
 // instead of 256 (+13 %), and the number of rounds hardly drops because levels travel along winding paths, not tile
 // diameters.
+#ifndef PCSEG_WS_SWEEP_MASKS
+// change tracking of the quadrant sweep (A/B builds): 0 = per-lane xor / or, every cell of a changed batch goes through its
+// LDS atomic (round 2); 1 = scalar lane masks from one v_cmp per step; 2 = 1 + only the lanes that lowered a cell issue
+// the atomic
+#define PCSEG_WS_SWEEP_MASKS 2
+#endif
 #ifndef PCSEG_WS_FSM
 #define PCSEG_WS_FSM 1  // 1: quadrant (raster-order wavefront) sweeps, 0: line sweeps -- see ws_quadrant_sweep
 #endif
@@ -304,6 +310,9 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
         unsigned wr[8];
         bool lowered[8];  // per lane "this step lowered its cell": lives as a lane mask in an SGPR pair (the v_cmp's result)
         unsigned long long batch_diff = 0;
+#if PCSEG_WS_SWEEP_MASKS == 0
+        unsigned lane_diff = 0;
+#endif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             // lane l takes lane l - 1's result of the previous step; lane 0 has no row above (wave_shr:1, `old` = +inf)
@@ -315,18 +324,27 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
             const unsigned m = min(up, lf);
             const unsigned cand = min(max(v, m), max(min(v, m), cur));  // median(value, m, cur) = min(cur, max(value, m))
             wr[k] = cand;
+#if PCSEG_WS_SWEEP_MASKS == 0
+            lane_diff |= cur ^ cand;
+            lowered[k] = true;
+#else
             lowered[k] = cur != cand;
             batch_diff |= __ballot(lowered[k]);
+#endif
             left = cand;
             prev = cand;
         }
+#if PCSEG_WS_SWEEP_MASKS == 0
+        batch_diff = __ballot(lane_diff != 0);
+#endif
         if (batch_diff != 0) {
             // Only the lanes that lowered their cell go to the LDS (the compare is the one above: its lane mask becomes the
             // exec mask of the atomic) -- late iterations lower a handful of cells, and the LDS array, not the VALU, is what
             // the four waves of a tile queue for.  Still an atomic min: another wave may have lowered the cell since the
             // batch was read.  (The level is the first word of the cell: the read's address and offset serve as they are.)
 #define PCSEG_DS_MIN(k)                                                                                                             \
-            if (lowered[k]) asm volatile("ds_min_u32 %0, %1 offset:%2" : : "v"(ba[k]), "v"(wr[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
+            if (PCSEG_WS_SWEEP_MASKS < 2 || lowered[k])                                                                                 \
+                asm volatile("ds_min_u32 %0, %1 offset:%2" : : "v"(ba[k]), "v"(wr[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
             PCSEG_DS_MIN(0) PCSEG_DS_MIN(1) PCSEG_DS_MIN(2) PCSEG_DS_MIN(3)
             PCSEG_DS_MIN(4) PCSEG_DS_MIN(5) PCSEG_DS_MIN(6) PCSEG_DS_MIN(7)
 #undef PCSEG_DS_MIN
