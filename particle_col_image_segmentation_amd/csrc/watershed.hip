@@ -136,8 +136,10 @@ __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__res
 #ifndef PCSEG_WS_SWEEP_MASKS
 // change tracking of the quadrant sweep (A/B builds): 0 = per-lane xor / or, every cell of a changed batch goes through its
 // LDS atomic (round 2); 1 = scalar lane masks from one v_cmp per step; 2 = 1 + only the lanes that lowered a cell issue
-// the atomic
-#define PCSEG_WS_SWEEP_MASKS 2
+// the atomic.  Same box, relaxation us per launch / overlapped ms per step (profiles/r03/ab_run.sh): 0: 119.7 / 5.85-5.93,
+// 1: 116.7 / 5.83-5.84, 2: 124.1 / 6.09-6.31 -- an exec-masked ds_min costs the LDS what a full one does, and the eight
+// scalar branches per batch come on top: 1 stays
+#define PCSEG_WS_SWEEP_MASKS 1
 #endif
 #ifndef PCSEG_WS_FSM
 #define PCSEG_WS_FSM 1  // 1: quadrant (raster-order wavefront) sweeps, 0: line sweeps -- see ws_quadrant_sweep
@@ -338,10 +340,9 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
         batch_diff = __ballot(lane_diff != 0);
 #endif
         if (batch_diff != 0) {
-            // Only the lanes that lowered their cell go to the LDS (the compare is the one above: its lane mask becomes the
-            // exec mask of the atomic) -- late iterations lower a handful of cells, and the LDS array, not the VALU, is what
-            // the four waves of a tile queue for.  Still an atomic min: another wave may have lowered the cell since the
-            // batch was read.  (The level is the first word of the cell: the read's address and offset serve as they are.)
+            // unconditional LDS atomic min per cell of a changed batch (variant 2 predicates it per lane: measured slower);
+            // still monotone when another wave lowered the cell since the batch was read.  (The level is the first word of
+            // the cell: the read's address and offset serve the atomic as they are.)
 #define PCSEG_DS_MIN(k)                                                                                                             \
             if (PCSEG_WS_SWEEP_MASKS < 2 || lowered[k])                                                                                 \
                 asm volatile("ds_min_u32 %0, %1 offset:%2" : : "v"(ba[k]), "v"(wr[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
