@@ -170,6 +170,13 @@ size_t pcseg_dilate_ccl_runs_workspace_bytes(int B, int H, int W);
 int pcseg_dilate_ccl_runs_u8(const uint8_t *in, uint64_t value_bits, int radius, uint32_t *dilated_bits,
                              int32_t *run_parent, int B, int H, int W, void *workspace, size_t workspace_bytes,
                              pcseg_stream_t stream);
+/* the same for n_masks (<= 4) masks of one class map at once -- get_cell_clusters_from_distances dilates and labels one
+ * mask per cell type plus the union of all types (tiff_analysis.py:806-822): the map is read once, every pass behind the
+ * bit planes is ONE launch over n_masks * B frames.  value_bits: HOST array [n_masks]; dilated_bits (n_masks, B,
+ * ceil(H/32), W); run_parent (n_masks, B, H, W).  W % 4 == 0.  Workspace: pcseg_dilate_ccl_runs_workspace_bytes(B * n_masks, H, W). */
+int pcseg_dilate_ccl_runs_multi_u8(const uint8_t *in, const uint64_t *value_bits, int n_masks, int radius,
+                                   uint32_t *dilated_bits, int32_t *run_parent, int B, int H, int W,
+                                   void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
 
 /* ---- A8: fill_particle_area (tiff_analysis.py:982-1015) in one pass pair:
  * out = ds with overlap pixels set to overlap_label, where overlap =
@@ -244,6 +251,15 @@ int pcseg_merge_groups_fused(const uint32_t *dilated_bits, const int32_t *run_pa
                              const int32_t *region_lists, const int32_t *n_lists, int slot, int n_slots,
                              int32_t *group_of, int32_t *n_groups, int64_t *group_stats, int B, int H, int W, int cap,
                              void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
+
+/* pcseg_merge_groups_fused for n_masks (<= 4) masks in ONE launch: dilated_bits (n_masks, B, ceil(H/32), W) and run_parent
+ * (n_masks, B, H, W) as pcseg_dilate_ccl_runs_multi_u8 leaves them, mask m grouped over the list of type slot slots[m]
+ * (HOST array); group_of (n_masks, B, cap), n_groups (n_masks, B), group_stats (n_masks, B, cap, 8).
+ * Workspace: pcseg_merge_groups_workspace_bytes(B * n_masks, cap). */
+int pcseg_merge_groups_fused_multi(const uint32_t *dilated_bits, const int32_t *run_parent, const int64_t *stats,
+                                   const int32_t *region_lists, const int32_t *n_lists, const int32_t *slots, int n_masks,
+                                   int n_slots, int32_t *group_of, int32_t *n_groups, int64_t *group_stats, int B, int H,
+                                   int W, int cap, void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
 
 /* member sums of the groups: group_stats int64 (B, list_cap, 8) = area, sum_row,
  * sum_col, min_row, min_col, max_row+1, max_col+1, members (tiff_analysis.py:855-872) */

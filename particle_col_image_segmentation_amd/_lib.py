@@ -58,6 +58,8 @@ SIGNATURES = {
     "pcseg_dilate_ccl_runs_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_dilate_ccl_runs_u8": (c_int, [_P, c_uint64, _I, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_merge_groups_runs": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, c_size_t, _P]),
+    "pcseg_dilate_ccl_runs_multi_u8": (c_int, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
+    "pcseg_merge_groups_fused_multi": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_merge_groups_fused": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_group_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "pcseg_classify_regions": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),

@@ -449,6 +449,47 @@ __global__ void __launch_bounds__(256) set_bits4_kernel(const uint8_t *__restric
     *reinterpret_cast<uint4 *>(bits + ((int64_t)b * nch + ch) * W + c) = make_uint4(w0, w1, w2, w3);
 }
 
+// several masks of one class map at once (the proximity merge wants one mask per cell type plus the union of all types):
+// the map is read ONCE, mask m goes to bits + m * (B * nch * W) -- behind it the dilation / run passes simply see
+// n_masks * B frames
+struct MaskSet {
+    unsigned long long bits[4];
+    int n;
+};
+__global__ void __launch_bounds__(256) set_bits4_multi_kernel(const uint8_t *__restrict__ in, MaskSet masks, unsigned *__restrict__ bits,
+                                                               int H, int W, int nch, int B)
+{
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    if (c >= W) return;
+    const uint8_t *src = in + (int64_t)b * H * W + c;
+    unsigned w[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[m][j] = 0;
+#pragma unroll 4
+    for (int j = 0; j < 32; ++j) {
+        const int r = ch * 32 + j;
+        if (r < H) {
+            const unsigned v = *reinterpret_cast<const unsigned *>(src + (int64_t)r * W);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned a = (v >> (8 * q)) & 255u;
+                const unsigned long long sel = a < 64 ? (1ull << a) : 0ull;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if (m < masks.n && (masks.bits[m] & sel)) w[m][q] |= 1u << j;
+            }
+        }
+    }
+    const int64_t plane = (int64_t)B * nch * W;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (m < masks.n)
+            *reinterpret_cast<uint4 *>(bits + m * plane + ((int64_t)b * nch + ch) * W + c) = make_uint4(w[m][0], w[m][1], w[m][2], w[m][3]);
+}
+
 // out = dilate(in, disk(radius)): for every row offset dy the columns within half(dy) = floor(sqrt(r^2 - dy^2)) are
 // OR-ed, then shifted by dy rows across the 32-row words (skimage disk: x^2 + y^2 <= r^2; outside the image = 0)
 __global__ void __launch_bounds__(256) dilate_bits_kernel(const unsigned *__restrict__ in, unsigned *__restrict__ out,
@@ -985,6 +1026,40 @@ int pcseg_dilate_ccl_runs_u8(const uint8_t *in, uint64_t value_bits, int radius,
     PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, (unsigned *)dilated_bits, radius, H, W, nch);
     PCSEG_CHECK_LAUNCH();
     PCSEG_LAUNCH(bitrun_tile_kernel, dim3((W + BR_TW - 1) / BR_TW, (nch + BR_CH - 1) / BR_CH, B), dim3(256), 0, s,
+                 (const unsigned *)dilated_bits, (int *)run_parent, H, W, nch);
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_LAUNCH(bitrun_border_kernel, g, dim3(256), 0, s, (const unsigned *)dilated_bits, (int *)run_parent, H, W, nch);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
+int pcseg_dilate_ccl_runs_multi_u8(const uint8_t *in, const uint64_t *value_bits, int n_masks, int radius, uint32_t *dilated_bits,
+                                   int32_t *run_parent, int B, int H, int W, void *workspace, size_t workspace_bytes,
+                                   pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(in && value_bits && dilated_bits && run_parent && workspace && n_masks >= 1 && n_masks <= 4 && radius >= 0 &&
+                      radius <= 15 && check_shape(B, H, W) && check_shape(B * n_masks, H, W),
+                  "bad arguments (1..4 masks, radius <= 15)");
+    PCSEG_REQUIRE((W & 3) == 0 && ((uintptr_t)in & 3) == 0, "W must be a multiple of 4 (use pcseg_dilate_ccl_runs_u8 per mask otherwise)");
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = (H + 31) / 32;
+    const int BM = B * n_masks;
+    Carver cv(workspace, workspace_bytes);
+    unsigned *bits = cv.take<unsigned>((size_t)BM * nch * W);
+    if (!cv.ok() || ((uintptr_t)bits & 15)) {
+        set_error("dilate_ccl_runs_multi: workspace too small or misaligned (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    MaskSet masks;
+    masks.n = n_masks;
+    for (int m = 0; m < 4; ++m) masks.bits[m] = m < n_masks ? (unsigned long long)value_bits[m] : 0ull;
+    PCSEG_LAUNCH(set_bits4_multi_kernel, dim3((W / 4 + 255) / 256, nch, B), dim3(256), 0, s, in, masks, bits, H, W, nch, B);
+    PCSEG_CHECK_LAUNCH();
+    // everything behind the bit planes sees n_masks * B independent frames
+    dim3 g((W + 255) / 256, nch, BM);
+    PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, (unsigned *)dilated_bits, radius, H, W, nch);
+    PCSEG_CHECK_LAUNCH();
+    PCSEG_LAUNCH(bitrun_tile_kernel, dim3((W + BR_TW - 1) / BR_TW, (nch + BR_CH - 1) / BR_CH, BM), dim3(256), 0, s,
                  (const unsigned *)dilated_bits, (int *)run_parent, H, W, nch);
     PCSEG_CHECK_LAUNCH();
     PCSEG_LAUNCH(bitrun_border_kernel, g, dim3(256), 0, s, (const unsigned *)dilated_bits, (int *)run_parent, H, W, nch);

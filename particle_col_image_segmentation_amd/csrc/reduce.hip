@@ -212,10 +212,10 @@ constexpr int COL_ROWS = PCSEG_COL_ROWS;
 #ifndef PCSEG_RED_WAVES
 #define PCSEG_RED_WAVES 2
 #endif
-// (the plane-free instantiation keeps no float64 accumulators: eight blocks per CU instead of two -- it is a latency-bound
-// stream of 4 bytes per pixel)
+// (the plane-free instantiation keeps no float64 accumulators: four blocks per CU instead of two -- it is a latency-bound
+// stream of 4 bytes per pixel; eight would cap it at 64 registers and spill: 502 us per launch against 190)
 template <int NC>
-__global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 8) region_reduce_col_kernel(const int *__restrict__ labels, const float *__restrict__ planes,
+__global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_reduce_col_kernel(const int *__restrict__ labels, const float *__restrict__ planes,
                                                                  const uint8_t *__restrict__ cls, unsigned long long sel, int C,
                                                                  int H, int W, int cap, long long *__restrict__ stats,
                                                                  double *__restrict__ sums, int *__restrict__ overflow)
@@ -661,17 +661,28 @@ __device__ __forceinline__ int block_exclusive_scan1024(int v, int *total, int *
     return base + inc - v;
 }
 
-__global__ void __launch_bounds__(MG_THREADS) merge_fused_kernel(const unsigned *__restrict__ run_bits, const int *__restrict__ run_parent,
+// (blockIdx.y = mask: the bit planes / run parents / outputs of mask m sit m * B frames further, its list is slot_of_mask[m])
+struct MergeSlots {
+    int slot[4];
+};
+__global__ void __launch_bounds__(MG_THREADS) merge_fused_kernel(const unsigned *__restrict__ run_bits_all, const int *__restrict__ run_parent_all,
                                                                  const long long *__restrict__ stats, const int *__restrict__ region_list,
-                                                                 const int *__restrict__ n_list, int slot, int n_slots,
-                                                                 int *__restrict__ group_of, int *__restrict__ n_groups,
-                                                                 long long *__restrict__ gstats, int *__restrict__ key_ws,
-                                                                 int *__restrict__ first_ws, int *__restrict__ gid_ws, int H, int W, int cap,
+                                                                 const int *__restrict__ n_list, MergeSlots slot_of_mask, int n_slots,
+                                                                 int *__restrict__ group_of_all, int *__restrict__ n_groups_all,
+                                                                 long long *__restrict__ gstats_all, int *__restrict__ key_ws_all,
+                                                                 int *__restrict__ first_ws_all, int *__restrict__ gid_ws_all, int H, int W, int cap,
                                                                  int list_cap)
 {
     __shared__ int s_key[MG_LDS], s_first[MG_LDS + 1], s_gid[MG_LDS];
     __shared__ int wsum[MG_THREADS / 64];
     const int b = blockIdx.x;
+    const int mask = blockIdx.y, B = gridDim.x, slot = slot_of_mask.slot[mask];
+    const int64_t mf = (int64_t)mask * B;  // frames in front of this mask's arrays
+    const unsigned *run_bits = run_bits_all + mf * ((H + 31) / 32) * W;
+    const int *run_parent = run_parent_all + mf * H * W;
+    int *group_of = group_of_all + mf * list_cap, *n_groups = n_groups_all + mf;
+    long long *gstats = gstats_all + mf * list_cap * 8;
+    int *key_ws = key_ws_all + mf * list_cap, *first_ws = first_ws_all + mf * (list_cap + 1), *gid_ws = gid_ws_all + mf * list_cap;
     const int R = min(n_list[b * n_slots + slot], list_cap);
     const int *lst = region_list + ((int64_t)b * n_slots + slot) * cap;
     const bool in_lds = R <= MG_LDS;  // block-uniform
@@ -1078,28 +1089,44 @@ int pcseg_merge_groups_runs(const uint32_t *dilated_bits, const int32_t *run_par
     return PCSEG_OK;
 }
 
+int pcseg_merge_groups_fused_multi(const uint32_t *dilated_bits, const int32_t *run_parent, const int64_t *stats,
+                                   const int32_t *region_lists, const int32_t *n_lists, const int32_t *slots, int n_masks, int n_slots,
+                                   int32_t *group_of, int32_t *n_groups, int64_t *group_stats, int B, int H, int W, int cap,
+                                   void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(dilated_bits && run_parent && stats && region_lists && n_lists && slots && group_of && n_groups && group_stats &&
+                      workspace && cap >= 1 && n_slots >= 1 && n_masks >= 1 && n_masks <= 4 && check_shape(B, H, W),
+                  "bad arguments (1..4 masks)");
+    MergeSlots ms;
+    for (int m = 0; m < 4; ++m) {
+        ms.slot[m] = m < n_masks ? slots[m] : 0;
+        PCSEG_REQUIRE(ms.slot[m] >= 0 && ms.slot[m] < n_slots, "list slot out of range");
+    }
+    const int list_cap = cap;
+    const size_t BM = (size_t)B * n_masks;
+    Carver cv(workspace, workspace_bytes);
+    int *key = cv.take<int>(BM * list_cap);
+    int *gid = cv.take<int>(BM * list_cap);
+    int *first = cv.take<int>(BM * (list_cap + 1));
+    if (!cv.ok()) {
+        set_error("merge_groups_fused: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
+        return PCSEG_ERR_WORKSPACE;
+    }
+    PCSEG_LAUNCH(merge_fused_kernel, dim3(B, n_masks), dim3(MG_THREADS), 0, (hipStream_t)stream, (const unsigned *)dilated_bits,
+                 (const int *)run_parent, (const long long *)stats, (const int *)region_lists, (const int *)n_lists, ms, n_slots,
+                 (int *)group_of, (int *)n_groups, (long long *)group_stats, key, first, gid, H, W, cap, list_cap);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
 int pcseg_merge_groups_fused(const uint32_t *dilated_bits, const int32_t *run_parent, const int64_t *stats,
                              const int32_t *region_lists, const int32_t *n_lists, int slot, int n_slots, int32_t *group_of,
                              int32_t *n_groups, int64_t *group_stats, int B, int H, int W, int cap, void *workspace,
                              size_t workspace_bytes, pcseg_stream_t stream)
 {
-    PCSEG_REQUIRE(dilated_bits && run_parent && stats && region_lists && n_lists && group_of && n_groups && group_stats &&
-                      workspace && cap >= 1 && n_slots >= 1 && slot >= 0 && slot < n_slots && check_shape(B, H, W),
-                  "bad arguments");
-    const int list_cap = cap;
-    Carver cv(workspace, workspace_bytes);
-    int *key = cv.take<int>((size_t)B * list_cap);
-    int *gid = cv.take<int>((size_t)B * list_cap);
-    int *first = cv.take<int>((size_t)B * (list_cap + 1));
-    if (!cv.ok()) {
-        set_error("merge_groups_fused: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
-        return PCSEG_ERR_WORKSPACE;
-    }
-    PCSEG_LAUNCH(merge_fused_kernel, dim3(B), dim3(MG_THREADS), 0, (hipStream_t)stream, (const unsigned *)dilated_bits,
-                 (const int *)run_parent, (const long long *)stats, (const int *)region_lists, (const int *)n_lists, slot, n_slots,
-                 (int *)group_of, (int *)n_groups, (long long *)group_stats, key, first, gid, H, W, cap, list_cap);
-    PCSEG_CHECK_LAUNCH();
-    return PCSEG_OK;
+    const int32_t slots[1] = {slot};
+    return pcseg_merge_groups_fused_multi(dilated_bits, run_parent, stats, region_lists, n_lists, slots, 1, n_slots, group_of, n_groups,
+                                          group_stats, B, H, W, cap, workspace, workspace_bytes, stream);
 }
 
 int pcseg_classify_regions(const int64_t *stats, const uint8_t *cls_out, const int32_t *counts, const uint8_t *class_slot,

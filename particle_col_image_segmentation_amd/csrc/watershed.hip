@@ -1139,18 +1139,43 @@ __device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *_
     }
     __syncthreads();
     const SweepLine ln = ws_line();
-    bool changed_any = false;
-    for (int iter = 0; iter < 100000; ++iter) {
-        bool changed = false;
-        unsigned prevK = sK[ln.start], prevL = sL[ln.start];
+    // Which cells of the lane's line take their predecessor's key does not change during the visit (levels and lake flags
+    // are constants here): one 64-bit mask per lane, built once.  An iteration then only reads the keys -- eight at a time,
+    // all eight reads in flight together (what another wave writes meanwhile is picked up an iteration later: the update
+    // is a monotone min) -- instead of three dependent LDS reads per cell: a tile's fixed point is tens of iterations of
+    // one wave per direction, i.e. pure LDS latency (60 us per grid round before, for a few dozen tiles).
+    unsigned long long link = 0;
+    {
+        unsigned pl = sL[ln.start];
         int i = ln.start;
 #pragma unroll 8
         for (int k = 0; k < WS_T; ++k) {
             i += ln.step;
-            unsigned cur = sK[i], l = sL[i];
-            if (sLake[i] && l == prevL && prevK < cur) { sK[i] = prevK; cur = prevK; changed = true; }
-            prevK = cur;
-            prevL = l;
+            const unsigned l = sL[i];
+            if (sLake[i] && l == pl) link |= 1ull << k;
+            pl = l;
+        }
+    }
+    bool changed_any = false;
+    for (int iter = 0; iter < 100000; ++iter) {
+        bool changed = false;
+        unsigned prevK = sK[ln.start];
+        int i = ln.start;
+#pragma unroll 1
+        for (int k0 = 0; k0 < WS_T; k0 += 8, i += 8 * ln.step) {
+            unsigned ck[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ck[j] = sK[i + (j + 1) * ln.step];
+            const unsigned bits = (unsigned)(link >> k0) & 255u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (((bits >> j) & 1u) && prevK < ck[j]) {
+                    sK[i + (j + 1) * ln.step] = prevK;
+                    ck[j] = prevK;
+                    changed = true;
+                }
+                prevK = ck[j];
+            }
         }
         if (!__syncthreads_or(changed)) break;
         changed_any = true;
@@ -1608,8 +1633,12 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
 }
 
 // grid rounds enqueued before the per-frame tail kernels take over (see ws_relax_tail_kernel): the benchmark batch needs
-// 10 relaxation rounds; a round without marks costs a few microseconds
-constexpr int WS_GRID_ROUNDS = 12, WS_K2_GRID_ROUNDS = 4;
+// 10 relaxation rounds; a round without marks costs a few microseconds.  The second level sees a few dozen tiles of a
+// few frames (benchmark batch: 31 tiles in 7 frames): two grid rounds, the per-frame tail kernel takes whatever is left
+#ifndef PCSEG_WS_K2_ROUNDS
+#define PCSEG_WS_K2_ROUNDS 2
+#endif
+constexpr int WS_GRID_ROUNDS = 12, WS_K2_GRID_ROUNDS = PCSEG_WS_K2_ROUNDS;
 
 int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *markers, const uint8_t *mask, int32_t *out,
                          int32_t *tie_flags, int B, int H, int W, int mode, void *workspace, size_t workspace_bytes,

@@ -345,6 +345,52 @@ def merge_groups_runs(bits, run_parent, stats, region_list, n_list):
     return group_of, n_groups
 
 
+def dilated_runs_multi(x, value_bits_list, radius):
+    """dilated_runs for several masks of one class map in one go (the class map is read once; every later pass is ONE launch
+    over all masks): returns (bits int32 (M, B, ceil(H/32), W), run_parent int32 (M, B, H, W))."""
+    import numpy as np
+    x = _req(x, torch.uint8, 3)
+    B, H, W = x.shape
+    M = len(value_bits_list)
+    lib = _lib.load()
+    bits = torch.empty((M, B, (H + 31) // 32, W), dtype=torch.int32, device=x.device)
+    run_parent = torch.empty((M, B, H, W), dtype=torch.int32, device=x.device)
+    nbytes = lib.pcseg_dilate_ccl_runs_workspace_bytes(B * M, H, W)
+    ws = _ws(nbytes, x.device)
+    vb = np.array([int(v) for v in value_bits_list], np.uint64)
+    _lib.check(lib.pcseg_dilate_ccl_runs_multi_u8(_ptr(x), ctypes.c_void_p(vb.ctypes.data), M, int(radius), _ptr(bits), _ptr(run_parent),
+                                                  B, H, W, _ptr(ws), nbytes, _stream()), "dilated_runs_multi")
+    return bits, run_parent
+
+
+def merge_groups_fused_multi(bits, run_parent, stats, region_lists, n_lists, slots):
+    """merge_groups_fused for the M masks of dilated_runs_multi in one launch; mask m is grouped over the list of type slot
+    ``slots[m]``.  Returns (group_of (M,B,cap), n_groups (M,B), group_stats (M,B,cap,8))."""
+    import numpy as np
+    bits = _req(bits, torch.int32, 4)
+    run_parent = _req(run_parent, torch.int32, 4)
+    stats = _req(stats, torch.int64, 3)
+    region_lists = _req(region_lists, torch.int32, 3)
+    n_lists = _req(n_lists, torch.int32, 2)
+    M, B, H, W = run_parent.shape
+    cap = stats.shape[1]
+    n_slots = region_lists.shape[1]
+    if len(slots) != M or bits.shape[0] != M or region_lists.shape[2] != cap or tuple(n_lists.shape) != (B, n_slots):
+        raise ValueError("masks / lists / region table do not match")
+    dev = stats.device
+    lib = _lib.load()
+    group_of = torch.empty((M, B, cap), dtype=torch.int32, device=dev)
+    n_groups = torch.empty((M, B), dtype=torch.int32, device=dev)
+    gstats = torch.empty((M, B, cap, 8), dtype=torch.int64, device=dev)
+    nbytes = lib.pcseg_merge_groups_workspace_bytes(B * M, cap)
+    ws = _ws(nbytes, dev)
+    sl = np.array([int(v) for v in slots], np.int32)
+    _lib.check(lib.pcseg_merge_groups_fused_multi(_ptr(bits), _ptr(run_parent), _ptr(stats), _ptr(region_lists), _ptr(n_lists),
+                                                  ctypes.c_void_p(sl.ctypes.data), M, n_slots, _ptr(group_of), _ptr(n_groups),
+                                                  _ptr(gstats), B, H, W, cap, _ptr(ws), nbytes, _stream()), "merge_groups_fused_multi")
+    return group_of, n_groups, gstats
+
+
 def merge_groups_fused(bits, run_parent, stats, region_lists, n_lists, slot):
     """get_merged_regions grouping + the member sums of the groups (tiff_analysis.py:843-878) for type slot ``slot`` in
     one launch: ``region_lists`` int32 (B, n_slots, cap) / ``n_lists`` int32 (B, n_slots) as classify_regions returns

@@ -228,8 +228,7 @@ class FramePipeline:
         res["shape"] = tuple(stack.shape)
         if not self.overlap:
             self._class_stage(stack, res)
-            for s in self._merge_slots():
-                self._merge_stage(stack, res, s)
+            self._merge_all(stack, res)
             self._fill_stage(stack, res)
             self._refine_chain(stack, res)
             self._sums_stage(stack, res)
@@ -302,8 +301,7 @@ class FramePipeline:
                 return out
             out = BatchResult(entries)
             self._class_stage(stack, out)
-            for sl in self._merge_slots():
-                self._merge_stage(stack, out, sl)
+            self._merge_all(stack, out)
             self._fill_stage(stack, out)
             self._refine_chain(stack, out)
             self._sums_stage(stack, out)
@@ -353,15 +351,8 @@ class FramePipeline:
                 s_fill.wait_event(ev_z)
                 _on(s_fill, out["denoised"])
             self._fill_stage(stack, out)
-        slots = self._merge_slots()
-        merge_streams = [s_class, s_m1, s_m2]
-        for k, slot in enumerate(slots):
-            st = merge_streams[k % len(merge_streams)]
-            with torch.cuda.stream(st):
-                if st is not s_class:
-                    st.wait_event(ev_c)
-                    _on(st, out["denoised"], out["stats"], out["region_list"], out["n_list"])
-                self._merge_stage(stack, out, slot)
+        with torch.cuda.stream(s_class):  # (the class-map stream is idle after the classification)
+            self._merge_all(stack, out)
         done = []
         for st in streams:
             ev = torch.cuda.Event()
@@ -385,6 +376,33 @@ class FramePipeline:
         # ---- classification, cluster cell counts, region lists (A3 tail, A4)
         res.update(ops.classify_regions(stats, cls_out, counts, tb))
         res["groups"] = {}
+
+    def _merge_all(self, stack, res):
+        """every proximity merge of the batch (one mask per cell type + the union of all types, A5 / A6) in five launches:
+        the class map is read once for all masks, dilation / run components / cross-tile links / grouping each run once over
+        masks x frames"""
+        slots = self._merge_slots()
+        if not slots:
+            return
+        B, C, H, W = stack.shape
+        tb = self.tables_
+        if W % 4:
+            for s in slots:
+                self._merge_stage(stack, res, s)
+            return
+        masks = []
+        for s in slots:
+            bits = 0
+            for v in ([tb.slot_value[s]] if s < 4 else tb.slot_value):
+                bits |= 1 << v
+            masks.append(bits)
+        keep = [k for k, m in enumerate(masks) if m]
+        if not keep:
+            return
+        dbits, run_par = ops.dilated_runs_multi(res["denoised"], [masks[k] for k in keep], ta.CELL_CLUSTER_DISTANCE_THRESHOLD // 2)
+        gof, ng, gst = ops.merge_groups_fused_multi(dbits, run_par, res["stats"], res["region_list"], res["n_list"], [slots[k] for k in keep])
+        for m, k in enumerate(keep):
+            res["groups"][slots[k]] = {"group_of": gof[m], "n_groups": ng[m], "group_stats": gst[m]}
 
     def _merge_stage(self, stack, res, s):
         """proximity merge of one cell type (s < 4) or of all types together (s = 4) (A5, A6)"""
