@@ -119,14 +119,22 @@ int pcseg_region_reduce_sel(const int32_t *labels, const int32_t *counts, const 
 /* (pcseg_region_reduce_sel with planes == NULL but sums != NULL and C >= 1: the integer columns only, the first
  * counts[b] rows of sums are ZEROED -- for pcseg_region_sums2.)
  *
- * Plane sums of TWO label images over the same planes in ONE pass (.m:122-135 for the class-map components and for the
+ * Table initialisation alone: the first min(counts[b], cap) rows of stats (B, cap, 8) get the neutral element of the
+ * reduction (0 sums, empty bounding box), those of sums (B, cap, C) (C may be 0) are zeroed, overflow[b] (may be NULL)
+ * cleared; counts == NULL: every row. */
+int pcseg_region_init(const int32_t *counts, int cap, int C, int B, int H, int W, int64_t *stats, double *sums,
+                      int32_t *overflow, pcseg_stream_t stream);
+
+/* Plane sums of TWO label images over the same planes in ONE pass (.m:122-135 for the class-map components and for the
  * refined ROIs; the planes are the largest thing a reduction reads): sums_a (B, cap_a, C) += per-label sums of labels_a
  * restricted to the pixels whose class-map value is in sum_class_bits (0 = every pixel), sums_b (B, cap_b, C) += per-label
- * sums of labels_b.  Both tables must have been zeroed (see above); labels above the capacity are skipped (the integer
- * pass reports them).  W % 4 == 0, 16-byte aligned images. */
+ * sums of labels_b.  stats_b != NULL: image B's integer columns (pcseg_region_col) are accumulated in the same walk into
+ * stats_b (B, cap_b, 8) / overflow_b.  Every table must have been initialised (pcseg_region_init, or
+ * pcseg_region_reduce_sel for image A); without stats_b labels above the capacity are skipped silently.  W % 4 == 0,
+ * 16-byte aligned images. */
 int pcseg_region_sums2(const int32_t *labels_a, const uint8_t *cls, uint64_t sum_class_bits, int cap_a, double *sums_a,
-                       const int32_t *labels_b, int cap_b, double *sums_b, const float *planes, int C, int B, int H, int W,
-                       pcseg_stream_t stream);
+                       const int32_t *labels_b, int cap_b, double *sums_b, int64_t *stats_b, int32_t *overflow_b,
+                       const float *planes, int C, int B, int H, int W, pcseg_stream_t stream);
 
 /* ---- R1: binary_mask = boundary_map < threshold (refine_boundaries.py:44-45) */
 int pcseg_threshold_lt_f32(const float *img, float threshold, uint8_t *mask, int B, int H, int W,

@@ -37,7 +37,8 @@ SIGNATURES = {
     "pcseg_region_reduce": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "pcseg_region_reduce_n": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "pcseg_region_reduce_sel": (c_int, [_P, _P, _P, ctypes.c_uint64, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
-    "pcseg_region_sums2": (c_int, [_P, _P, ctypes.c_uint64, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "pcseg_region_init": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "pcseg_region_sums2": (c_int, [_P, _P, ctypes.c_uint64, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "pcseg_threshold_lt_f32": (c_int, [_P, c_float, _P, _I, _I, _I, _P]),
     "pcseg_edt_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_edt_sq_u8": (c_int, [_P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),

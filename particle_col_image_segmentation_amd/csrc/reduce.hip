@@ -394,30 +394,42 @@ __device__ __forceinline__ void sums_commit(const SumSlots &ls, double *gsum, in
     }
 }
 
-template <int NC>
+// STATS_B: image B's integer columns (area, centroid sums, bounding box, first pixel) are accumulated in the same walk
+// (its runs are tracked anyway): the refined ROIs' table then needs no pass of its own.
+template <int NC, bool STATS_B>
 __global__ void __launch_bounds__(256, 2) region_sums2_col_kernel(const int *__restrict__ labels_a, const uint8_t *__restrict__ cls,
                                                                   unsigned long long sel, const int *__restrict__ labels_b,
                                                                   const float *__restrict__ planes, int C, int H, int W, int cap_a,
-                                                                  int cap_b, double *__restrict__ sums_a, double *__restrict__ sums_b)
+                                                                  int cap_b, double *__restrict__ sums_a, double *__restrict__ sums_b,
+                                                                  long long *__restrict__ stats_b, int *__restrict__ overflow_b)
 {
     __shared__ int tags_a[RED_SLOTS], tags_b[RED_SLOTS];
     __shared__ double lsum_a[RED_SLOTS][RED_MAXC], lsum_b[RED_SLOTS][RED_MAXC];
+    __shared__ long long lstat_b[STATS_B ? RED_SLOTS : 1][8];
     const int b = blockIdx.z;
     const int64_t n = (int64_t)H * W;
     const int *la = labels_a + (int64_t)b * n, *lb = labels_b + (int64_t)b * n;
     const float *pl = planes + (int64_t)b * C * n;
     double *ga = sums_a + (int64_t)b * cap_a * C, *gb = sums_b + (int64_t)b * cap_b * C;
+    long long *gst_b = STATS_B ? stats_b + (int64_t)b * cap_b * 8 : nullptr;
     for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
         tags_a[i] = 0;
         tags_b[i] = 0;
         for (int k = 0; k < RED_MAXC; ++k) { lsum_a[i][k] = 0.0; lsum_b[i][k] = 0.0; }
+        if (STATS_B) {
+            lstat_b[i][0] = 0; lstat_b[i][1] = 0; lstat_b[i][2] = 0; lstat_b[i][3] = H; lstat_b[i][4] = W; lstat_b[i][5] = 0;
+            lstat_b[i][6] = 0; lstat_b[i][7] = 0x7FFFFFFFFFFFFFFFLL;
+        }
     }
     __syncthreads();
     const SumSlots sa{tags_a, lsum_a}, sb{tags_b, lsum_b};
+    const RegionSlots sbb{tags_b, lstat_b, lsum_b};
     const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int r0 = blockIdx.y * COL_ROWS, r1 = min(H, r0 + COL_ROWS);
     if (c < W) {
         int cur_a[4] = {0, 0, 0, 0}, cur_b[4] = {0, 0, 0, 0};
+        int start_b[4] = {0, 0, 0, 0}, area_b[4] = {0, 0, 0, 0};
+        long long srow_b[4] = {0, 0, 0, 0};
         double acc_a[4][NC], acc_b[4][NC];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -465,13 +477,27 @@ __global__ void __launch_bounds__(256, 2) region_sums2_col_kernel(const int *__r
                     for (int k = 0; k < NC; ++k) acc_a[j][k] = 0.0;
                 }
                 if (bb[j] != cur_b[j]) {
-                    sums_commit<NC>(sb, gb, cap_b, C, cur_b[j], acc_b[j]);
+                    if (STATS_B) {
+                        if (cur_b[j] > 0)
+                            region_commit<NC>(sbb, gst_b, gb, overflow_b, b, cap_b, C, cur_b[j], area_b[j], srow_b[j],
+                                              (long long)(c + j) * area_b[j], start_b[j], start_b[j] + area_b[j], c + j, c + j,
+                                              (long long)start_b[j] * W + c + j, acc_b[j]);
+                        start_b[j] = r;
+                        area_b[j] = 0;
+                        srow_b[j] = 0;
+                    } else {
+                        sums_commit<NC>(sb, gb, cap_b, C, cur_b[j], acc_b[j]);
+                    }
                     cur_b[j] = bb[j];
 #pragma unroll
                     for (int k = 0; k < NC; ++k) acc_b[j][k] = 0.0;
                 }
                 if (r < r1) {
                     const bool in_a = aa[j] > 0 && ((want >> j) & 1u), in_b = bb[j] > 0;
+                    if (STATS_B && in_b) {
+                        area_b[j] += 1;
+                        srow_b[j] += r;
+                    }
 #pragma unroll
                     for (int k = 0; k < NC; ++k) {
                         const float4 f = v[k];
@@ -489,9 +515,21 @@ __global__ void __launch_bounds__(256, 2) region_sums2_col_kernel(const int *__r
         if (l1)
             for (int k = 0; k < C; ++k)
                 if (lsum_a[i][k] != 0.0) atomicAdd(&ga[(int64_t)(l1 - 1) * C + k], lsum_a[i][k]);
-        if (l2)
+        if (l2) {
             for (int k = 0; k < C; ++k)
                 if (lsum_b[i][k] != 0.0) atomicAdd(&gb[(int64_t)(l2 - 1) * C + k], lsum_b[i][k]);
+            if (STATS_B) {
+                long long *t = gst_b + (int64_t)(l2 - 1) * 8;
+                atomicAdd((unsigned long long *)&t[0], (unsigned long long)lstat_b[i][0]);
+                atomicAdd((unsigned long long *)&t[1], (unsigned long long)lstat_b[i][1]);
+                atomicAdd((unsigned long long *)&t[2], (unsigned long long)lstat_b[i][2]);
+                atomic_min_i64(&t[3], lstat_b[i][3]);
+                atomic_min_i64(&t[4], lstat_b[i][4]);
+                atomic_max_i64(&t[5], lstat_b[i][5]);
+                atomic_max_i64(&t[6], lstat_b[i][6]);
+                atomic_min_i64(&t[7], lstat_b[i][7]);
+            }
+        }
     }
 }
 
@@ -1014,9 +1052,20 @@ int pcseg_region_reduce(const int32_t *labels, const uint8_t *cls, const float *
     return pcseg_region_reduce_n(labels, nullptr, cls, planes, C, B, H, W, cap, stats, cls_out, sums, overflow, stream);
 }
 
+int pcseg_region_init(const int32_t *counts, int cap, int C, int B, int H, int W, int64_t *stats, double *sums, int32_t *overflow,
+                      pcseg_stream_t stream)
+{
+    PCSEG_REQUIRE(stats && cap >= 1 && C >= 0 && C <= RED_MAXC && (C == 0 || sums) && check_shape(B, H, W), "bad arguments (C <= 8)");
+    hipStream_t s = (hipStream_t)stream;
+    if (overflow) PCSEG_CHECK_HIP(hipMemsetAsync(overflow, 0, sizeof(int32_t) * B, s));
+    PCSEG_LAUNCH(region_init_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, s, (long long *)stats, C ? sums : nullptr, counts, cap, C, H, W);
+    PCSEG_CHECK_LAUNCH();
+    return PCSEG_OK;
+}
+
 int pcseg_region_sums2(const int32_t *labels_a, const uint8_t *cls, uint64_t sum_class_bits, int cap_a, double *sums_a,
-                       const int32_t *labels_b, int cap_b, double *sums_b, const float *planes, int C, int B, int H, int W,
-                       pcseg_stream_t stream)
+                       const int32_t *labels_b, int cap_b, double *sums_b, int64_t *stats_b, int32_t *overflow_b,
+                       const float *planes, int C, int B, int H, int W, pcseg_stream_t stream)
 {
     PCSEG_REQUIRE(labels_a && labels_b && sums_a && sums_b && planes && cap_a >= 1 && cap_b >= 1 && C >= 1 && C <= RED_MAXC &&
                       check_shape(B, H, W),
@@ -1027,12 +1076,15 @@ int pcseg_region_sums2(const int32_t *labels_a, const uint8_t *cls, uint64_t sum
                   "W must be a multiple of 4 and the images 16-byte aligned (use pcseg_region_reduce_sel per image otherwise)");
     hipStream_t s = (hipStream_t)stream;
     const dim3 cgrid((W / 4 + 255) / 256, (H + COL_ROWS - 1) / COL_ROWS, B);
-    if (C <= 5)
-        PCSEG_LAUNCH(region_sums2_col_kernel<5>, cgrid, dim3(256), 0, s, labels_a, cls, (unsigned long long)sum_class_bits, labels_b, planes, C,
-                     H, W, cap_a, cap_b, sums_a, sums_b);
-    else
-        PCSEG_LAUNCH(region_sums2_col_kernel<8>, cgrid, dim3(256), 0, s, labels_a, cls, (unsigned long long)sum_class_bits, labels_b, planes, C,
-                     H, W, cap_a, cap_b, sums_a, sums_b);
+    const unsigned long long sel = sum_class_bits;
+#define PCSEG_SUMS2(NCV, ST)                                                                                                        \
+    PCSEG_LAUNCH((region_sums2_col_kernel<NCV, ST>), cgrid, dim3(256), 0, s, labels_a, cls, sel, labels_b, planes, C, H, W, cap_a, cap_b, \
+                 sums_a, sums_b, (long long *)stats_b, overflow_b)
+    if (C <= 5 && stats_b) PCSEG_SUMS2(5, true);
+    else if (C <= 5) PCSEG_SUMS2(5, false);
+    else if (stats_b) PCSEG_SUMS2(8, true);
+    else PCSEG_SUMS2(8, false);
+#undef PCSEG_SUMS2
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }

@@ -609,6 +609,8 @@ __global__ void __launch_bounds__(RelaxGeom<T>::THREADS) ws_relax_kernel(WsInput
 // a few tiles of a few frames, if anything -- is finished by this kernel: one block per frame walks the frame's marked
 // tiles round by round until a round marks nothing.  Rounds of one frame only depend on that frame's tiles, so the
 // block's own barrier is the only synchronisation (stores and loads of one workgroup go through the same L1).
+constexpr int WS_TAIL_LIST = 1024;  // marked tiles a tail kernel lists per round (more: it walks every tile)
+
 template <int T>
 __global__ void __launch_bounds__(RelaxGeom<T>::THREADS) ws_relax_tail_kernel(WsInputs in, unsigned *__restrict__ val,
                                                                               unsigned *__restrict__ L, uint8_t *__restrict__ dirtyA,
@@ -618,22 +620,35 @@ __global__ void __launch_bounds__(RelaxGeom<T>::THREADS) ws_relax_tail_kernel(Ws
                                                                               int max_rounds)
 {
     extern __shared__ __attribute__((aligned(16))) uint2 relax_lds[];
+    __shared__ int tail_list[WS_TAIL_LIST];
+    __shared__ int tail_count;
     const int b = blockIdx.x;
     uint8_t *din = dirtyA, *dout = dirtyB;
     for (int round = first_round;; ++round) {
         const WsTiling cur = (round & 1) ? t1 : t0, nxt = (round & 1) ? t0 : t1;
         const int ntiles = cur.nx * cur.ny;
         const uint8_t *marks = din + (int64_t)b * ntiles;
-        bool any = false;
-        for (int t = threadIdx.x; t < ntiles; t += RelaxGeom<T>::THREADS) any = any || marks[t] != 0;
-        if (!__syncthreads_or(any)) return;
+        // the round's work list: the marked tiles, gathered in parallel (walking ALL tiles and letting each look at its own
+        // mark costs a dependent global load per tile -- 256 round trips per round for a handful of marked tiles)
+        if (threadIdx.x == 0) tail_count = 0;
+        __syncthreads();
+        for (int t = threadIdx.x; t < ntiles; t += RelaxGeom<T>::THREADS)
+            if (marks[t] != 0) {
+                const int k = atomicAdd(&tail_count, 1);
+                if (k < WS_TAIL_LIST) tail_list[k] = t;
+            }
+        __syncthreads();
+        const int marked = tail_count;
+        if (marked == 0) return;
         if (round - first_round >= max_rounds) {  // cannot happen for a monotone fixed point; never spin for ever
             // L of this frame is not a fixed point: whatever the union-find makes of it must not be reported as exact --
             // the frame's tie flag is raised, so the exact flood (mode 0) recomputes it and mode 2 reports it
             if (threadIdx.x == 0) { *not_converged = 1; exact_flags[b] = 1; }
             return;
         }
-        for (int t = 0; t < ntiles; ++t) {
+        const int walk = marked <= WS_TAIL_LIST ? marked : ntiles;  // (a list that overflowed: every tile, each checks its mark)
+        for (int k = 0; k < walk; ++k) {
+            const int t = marked <= WS_TAIL_LIST ? tail_list[k] : k;
             ws_relax_tile<T>(relax_lds + RelaxGeom<T>::PAD, in, false, val, L, din, dout, any_changed, H, W, cur, nxt, 100000, t % cur.nx,
                              t / cur.nx, b);
             __syncthreads();  // the tile's stores (L, marks) before the next tile loads its halo / the next round scans
@@ -1207,20 +1222,33 @@ __global__ void __launch_bounds__(256) ws_k2_relax_tail_kernel(const int *__rest
                                                                 int max_rounds)
 {
     __shared__ WsK2Lds lds;
+    __shared__ int tail_list[WS_TAIL_LIST];
+    __shared__ int tail_count;
     ws_for_frames(frame_list, blockIdx.x, gridDim.x, [&](const int b) {
     uint8_t *din = dirtyA, *dout = dirtyB;
     const int ntiles = tilesX * tilesY;
     for (int round = 0;; ++round) {
         // (a mark on a tile outside the active set is never taken down -- such tiles are not visited -- and is no work)
         const uint8_t *marks = din + (int64_t)b * ntiles, *act = active + (int64_t)b * ntiles;
-        bool any = false;
-        for (int t = threadIdx.x; t < ntiles; t += 256) any = any || (marks[t] != 0 && act[t] != 0);
-        if (!__syncthreads_or(any)) return;
+        // the round's work list: marked active tiles, gathered in parallel (see ws_relax_tail_kernel)
+        __syncthreads();
+        if (threadIdx.x == 0) tail_count = 0;
+        __syncthreads();
+        for (int t = threadIdx.x; t < ntiles; t += 256)
+            if (marks[t] != 0 && act[t] != 0) {
+                const int k = atomicAdd(&tail_count, 1);
+                if (k < WS_TAIL_LIST) tail_list[k] = t;
+            }
+        __syncthreads();
+        const int marked = tail_count;
+        if (marked == 0) return;
         if (round >= max_rounds) {
             if (threadIdx.x == 0) { *not_converged = 1; exact_flags[b] = 1; }  // see ws_relax_tail_kernel
             return;
         }
-        for (int t = 0; t < ntiles; ++t) {
+        const int walk = marked <= WS_TAIL_LIST ? marked : ntiles;
+        for (int k = 0; k < walk; ++k) {
+            const int t = marked <= WS_TAIL_LIST ? tail_list[k] : k;
             ws_k2_relax_tile(lds, val, L, K2, active, din, dout, H, W, tilesX, tilesY, t % tilesX, t / tilesX, b);
             __syncthreads();
         }

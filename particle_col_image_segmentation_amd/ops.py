@@ -113,10 +113,24 @@ def compact_labels(roots):
     return labels, counts
 
 
-def region_sums2(labels_a, cls, sum_classes, sums_a, labels_b, sums_b, planes):
+def region_init(counts, cap, C, shape, device):
+    """Initialised (not yet filled) region tables of a (B, H, W) label batch: stats int64 (B, cap, 8) with the
+    reduction's neutral rows, sums float64 (B, cap, C) zeroed (rows below counts[b]), overflow int32 (B,) cleared."""
+    B, H, W = shape
+    counts = _req(counts, torch.int32, 1)
+    stats = torch.empty((B, cap, 8), dtype=torch.int64, device=device)
+    sums = torch.empty((B, cap, C), dtype=torch.float64, device=device)
+    overflow = torch.empty((B,), dtype=torch.int32, device=device)
+    lib = _lib.load()
+    _lib.check(lib.pcseg_region_init(_ptr(counts), cap, C, B, H, W, _ptr(stats), _ptr(sums), _ptr(overflow), _stream()), "region_init")
+    return stats, sums, overflow
+
+
+def region_sums2(labels_a, cls, sum_classes, sums_a, labels_b, sums_b, planes, stats_b=None, overflow_b=None):
     """Per-label plane sums of two label images in ONE pass over the planes (csrc/reduce.hip region_sums2_col_kernel):
-    ``sums_a`` / ``sums_b`` (float64 (B, cap, C), zeroed by ``region_reduce(..., zero_sums=C)``) are added to in place;
-    image A only under the class values in ``sum_classes`` (bit v = value v, 0 = everywhere)."""
+    ``sums_a`` / ``sums_b`` (float64 (B, cap, C), zeroed by ``region_reduce(..., zero_sums=C)`` or ``region_init``) are
+    added to in place; image A only under the class values in ``sum_classes`` (bit v = value v, 0 = everywhere).
+    ``stats_b`` / ``overflow_b`` (from ``region_init``): image B's integer columns are accumulated in the same walk."""
     labels_a = _req(labels_a, torch.int32, 3)
     labels_b = _req(labels_b, torch.int32, 3)
     planes = _req(planes, torch.float32, 4)
@@ -126,9 +140,14 @@ def region_sums2(labels_a, cls, sum_classes, sums_a, labels_b, sums_b, planes):
     B, C, H, W = planes.shape
     if tuple(labels_a.shape) != (B, H, W) or tuple(labels_b.shape) != (B, H, W) or sums_a.shape[2] != C or sums_b.shape[2] != C:
         raise ValueError("label images / sums tables do not match the planes")
+    if stats_b is not None:
+        stats_b = _req(stats_b, torch.int64, 3)
+        if tuple(stats_b.shape) != (B, sums_b.shape[1], 8):
+            raise ValueError("stats_b must be (B, cap_b, 8)")
     lib = _lib.load()
     _lib.check(lib.pcseg_region_sums2(_ptr(labels_a), _ptr(cls), int(sum_classes), sums_a.shape[1], _ptr(sums_a), _ptr(labels_b),
-                                      sums_b.shape[1], _ptr(sums_b), _ptr(planes), C, B, H, W, _stream()), "region_sums2")
+                                      sums_b.shape[1], _ptr(sums_b), _ptr(stats_b), _ptr(overflow_b), _ptr(planes), C, B, H, W,
+                                      _stream()), "region_sums2")
 
 
 def region_reduce(labels, counts=None, cls=None, planes=None, cap=None, sum_classes=0, zero_sums=0):

@@ -444,8 +444,11 @@ class FramePipeline:
         _, markers, n_markers = ops.local_maxima(d2, want_mask=False)
         ws_labels, tie_flags = ops.watershed(bm, markers, mask, mode=self.watershed_mode)
         res.update(mask=mask, markers=markers, n_markers=n_markers, ws_labels=ws_labels, tie_flags=tie_flags)
-        # ---- area / centroid sums of the refined ROIs; their isotope sums: _sums_stage
-        ws_stats, _, ws_sums, ws_overflow = ops.region_reduce(ws_labels, n_markers, cap=cap, zero_sums=C)
+        # ---- the refined ROIs' tables: initialised here, filled (integer columns and isotope sums) by _sums_stage
+        if W % 4 == 0:
+            ws_stats, ws_sums, ws_overflow = ops.region_init(n_markers, cap, C, (B, H, W), stack.device)
+        else:
+            ws_stats, _, ws_sums, ws_overflow = ops.region_reduce(ws_labels, n_markers, cap=cap, zero_sums=C)
         res.update(ws_stats=ws_stats, ws_sums=ws_sums, ws_overflow=ws_overflow)
 
     def _sums_stage(self, stack, res):
@@ -457,7 +460,8 @@ class FramePipeline:
             cell_bits |= 1 << int(v)
         B, C, H, W = stack.shape
         if W % 4 == 0:
-            ops.region_sums2(res["labels"], res["denoised"], cell_bits, res["cc_sums"], res["ws_labels"], res["ws_sums"], stack)
+            ops.region_sums2(res["labels"], res["denoised"], cell_bits, res["cc_sums"], res["ws_labels"], res["ws_sums"], stack,
+                             stats_b=res["ws_stats"], overflow_b=res["ws_overflow"])
             return
         # ragged widths: the per-image kernels (their plane pass adds nothing to the already counted integer columns'
         # cost worth a special path)

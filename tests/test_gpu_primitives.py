@@ -142,8 +142,17 @@ def test_region_sums2(ops):
         cb = torch.tensor([int(l.max()) for l in lb], dtype=torch.int32).cuda()
         sel = (1 << 1) | (1 << 2)
         stats_a, _, sums_a, _ = ops.region_reduce(dev(la), ca, dev(cm), zero_sums=5)
+        # image B: once with its integer columns made by the plane-free pass, once accumulated by the fused pass itself
         stats_b, _, sums_b, _ = ops.region_reduce(dev(lb), cb, zero_sums=5)
         ops.region_sums2(dev(la), dev(cm), sel, sums_a, dev(lb), sums_b, dev(st))
+        stats_b2, sums_b2, ovf_b2 = ops.region_init(cb, stats_b.shape[1], 5, (b, h, w), stats_b.device)
+        sums_a2 = torch.zeros_like(sums_a)
+        ops.region_sums2(dev(la), dev(cm), sel, sums_a2, dev(lb), sums_b2, dev(st), stats_b=stats_b2, overflow_b=ovf_b2)
+        assert int(ovf_b2.sum()) == 0
+        for i in range(b):
+            nb = int(lb[i].max())
+            np.testing.assert_array_equal(host(stats_b2)[i, :nb], host(stats_b)[i, :nb])
+            np.testing.assert_allclose(host(sums_b2)[i, :nb], host(sums_b)[i, :nb], rtol=1e-12, atol=0)
         for i in range(b):
             na, nb = int(la[i].max()), int(lb[i].max())
             np.testing.assert_array_equal(host(stats_a)[i, :na], orc.region_table(la[i]))
