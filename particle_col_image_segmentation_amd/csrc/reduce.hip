@@ -310,6 +310,31 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
                             for (int k = 0; k < (NC > 0 ? NC : 1); ++k) acc[i][k] += acc[j][k];
                             cur[j] = 0;
                         }
+                // ... and when a whole WAVE sits in one region (background, the particle: most waves of a class map) the 64
+                // lanes are reduced with shuffles and one lane commits: otherwise they all fire their eight atomics at the
+                // same LDS slot, which serialises them
+                const int l0 = __builtin_amdgcn_readfirstlane(cur[0]);
+                // (only a fully active wave: a shuffle from a lane beyond the frame's width would read nothing defined)
+                if (__ballot(true) == ~0ull && __all(cur[0] == l0 && l0 > 0 && cur[1] == 0 && cur[2] == 0 && cur[3] == 0)) {
+                    long long v_area = area[0], v_srow = srow[0], v_scol = scol[0], v_rmin = rmin[0], v_rmax = rmax1[0], v_cmin = cmin[0],
+                              v_cmax = cmax[0], v_first = first[0];
+                    for (int off = 32; off; off >>= 1) {
+                        v_area += __shfl_xor(v_area, off);
+                        v_srow += __shfl_xor(v_srow, off);
+                        v_scol += __shfl_xor(v_scol, off);
+                        v_rmin = min(v_rmin, __shfl_xor(v_rmin, off));
+                        v_rmax = max(v_rmax, __shfl_xor(v_rmax, off));
+                        v_cmin = min(v_cmin, __shfl_xor(v_cmin, off));
+                        v_cmax = max(v_cmax, __shfl_xor(v_cmax, off));
+                        v_first = min(v_first, __shfl_xor(v_first, off));
+#pragma unroll
+                        for (int k = 0; k < (NC > 0 ? NC : 1); ++k) acc[0][k] += __shfl_xor(acc[0][k], off);
+                    }
+                    if (lane_id() == 0)
+                        region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, l0, v_area, v_srow, v_scol, v_rmin, v_rmax, v_cmin, v_cmax,
+                                          v_first, acc[0]);
+                    break;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (cur[j] > 0)

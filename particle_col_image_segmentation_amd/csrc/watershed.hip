@@ -949,18 +949,21 @@ __global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict
 //   UF_ASSIGN      reset possible), pass 2: label the pixels of the components that are not bad
 enum { UF_OPTIMISTIC = 0, UF_REPAIR = 1, UF_DETECT = 2, UF_ASSIGN = 3 };
 
+//   UF_REPAIR also leaves, per pixel of a listed frame, "belongs to an unresolved component" in `in_bad` (if given): the
+//   second level's lake propagation only has to run inside those components (see ws_k2_relax_tile)
 template <int MODE>
 __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict__ frame_list, const int *__restrict__ parent, int *__restrict__ F,
                                                            const uint8_t *__restrict__ active, uint8_t *__restrict__ bad,
                                                            const int *__restrict__ markers, const uint8_t *__restrict__ mask,
                                                            int *__restrict__ tie_flags, uint8_t *__restrict__ mark_active, int64_t n,
-                                                           int W, int tilesX, int tilesY)
+                                                           int W, int tilesX, int tilesY, uint8_t *__restrict__ in_bad = nullptr)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     ws_for_frames(frame_list, blockIdx.y, gridDim.y, [&](const int b) {
     const int r = (int)(i / W), c = (int)(i % W);
     if (i >= n || !ws_active(active, b, r, c, tilesX, tilesY)) return;
     const int64_t fbase = (int64_t)b * n, g = fbase + i;
+    if (MODE == UF_REPAIR && in_bad) in_bad[g] = 0;
     int x = parent[g];
     if (x < 0) return;
     const int *par = parent + fbase;
@@ -972,6 +975,7 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
         if (bad[groot]) {
             F[g] = mask[g] ? markers[g] : 0;
             if (mark_active) mark_active[((int64_t)b * tilesY + r / WS_T) * tilesX + c / WS_T] = 1;
+            if (in_bad) in_bad[g] = 1;
         }
         return;
     }
@@ -1109,10 +1113,16 @@ struct WsK2Lds {
 };
 
 // one tile of one second-level round (block-uniform control flow, like ws_relax_tile)
+// `in_bad` (may be null: every lake): the per-pixel mark UF_REPAIR leaves.  K2 is only ever COMPARED between the
+// minimum-level neighbours of a pixel that is still unlabelled, i.e. inside one unresolved first-level component; a lake
+// (connected pixels of one level below it) and the entries that open it are linked by minimum-level links, so they lie
+// in ONE component, and the K2 of a component's pixels depends on nothing outside it.  An active 64 x 64 tile of a noise
+// field holds hundreds of lakes, the slowest of which used to set the iteration count of every visit (60 us per grid
+// round for a few dozen tiles); the unresolved components hold a handful.
 __device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
                                                  unsigned *__restrict__ K2, const uint8_t *__restrict__ active,
                                                  uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out, int H, int W,
-                                                 int tilesX, int tilesY, int tx, int ty, int b)
+                                                 int tilesX, int tilesY, int tx, int ty, int b, const uint8_t *__restrict__ in_bad)
 {
     unsigned *sL = lds.sL, *sK = lds.sK;
     uint8_t *sLake = lds.sLake;
@@ -1130,6 +1140,7 @@ __device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *_
         // load; see ws_relax_tile): a loop of dependent round trips here cost more than the sweeps
         constexpr int TRIPS = (WS_S * WS_S + 255) / 256;
         unsigned lv[TRIPS], kv[TRIPS], vv[TRIPS];
+        uint8_t bv[TRIPS];
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
             const int i = min((int)threadIdx.x + 256 * t, WS_S * WS_S - 1);
@@ -1138,6 +1149,7 @@ __device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *_
             lv[t] = L[p];
             kv[t] = K2[p];
             vv[t] = val[p];
+            bv[t] = in_bad ? in_bad[p] : (uint8_t)1;
         }
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
@@ -1148,7 +1160,7 @@ __device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *_
                 const bool in = r >= 0 && r < H && c >= 0 && c < W;
                 sL[lr * WS_P + lc] = in ? lv[t] : WS_INF;
                 sK[lr * WS_P + lc] = in ? kv[t] : WS_INF;
-                sLake[lr * WS_P + lc] = in && lv[t] != WS_INF && vv[t] < lv[t];
+                sLake[lr * WS_P + lc] = in && lv[t] != WS_INF && vv[t] < lv[t] && bv[t] != 0;
             }
         }
     }
@@ -1204,11 +1216,11 @@ __device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *_
 __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
                                                            unsigned *__restrict__ K2, const uint8_t *__restrict__ active,
                                                            uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
-                                                           int H, int W, int tilesX, int tilesY)
+                                                           int H, int W, int tilesX, int tilesY, const uint8_t *__restrict__ in_bad)
 {
     __shared__ WsK2Lds lds;
     ws_for_frames(frame_list, blockIdx.z, gridDim.z, [&](const int b) {
-        ws_k2_relax_tile(lds, val, L, K2, active, dirty_in, dirty_out, H, W, tilesX, tilesY, blockIdx.x, blockIdx.y, b);
+        ws_k2_relax_tile(lds, val, L, K2, active, dirty_in, dirty_out, H, W, tilesX, tilesY, blockIdx.x, blockIdx.y, b, in_bad);
         __syncthreads();  // the next listed frame reuses the tile arrays
     });
 }
@@ -1219,7 +1231,7 @@ __global__ void __launch_bounds__(256) ws_k2_relax_tail_kernel(const int *__rest
                                                                 const uint8_t *__restrict__ active, uint8_t *__restrict__ dirtyA,
                                                                 uint8_t *__restrict__ dirtyB, int *__restrict__ not_converged,
                                                                 int *__restrict__ exact_flags, int H, int W, int tilesX, int tilesY,
-                                                                int max_rounds)
+                                                                int max_rounds, const uint8_t *__restrict__ in_bad)
 {
     __shared__ WsK2Lds lds;
     __shared__ int tail_list[WS_TAIL_LIST];
@@ -1249,7 +1261,7 @@ __global__ void __launch_bounds__(256) ws_k2_relax_tail_kernel(const int *__rest
         const int walk = marked <= WS_TAIL_LIST ? marked : ntiles;
         for (int k = 0; k < walk; ++k) {
             const int t = marked <= WS_TAIL_LIST ? tail_list[k] : k;
-            ws_k2_relax_tile(lds, val, L, K2, active, din, dout, H, W, tilesX, tilesY, t % tilesX, t / tilesX, b);
+            ws_k2_relax_tile(lds, val, L, K2, active, din, dout, H, W, tilesX, tilesY, t % tilesX, t / tilesX, b, in_bad);
             __syncthreads();
         }
         uint8_t *tmp = din; din = dout; dout = tmp;
@@ -1818,8 +1830,11 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             const int span = ws_frame_span(frame_list, B);
             const dim3 tgrid(tilesX, tilesY, span), lgrid(lgrid_full.x, span), pgrid2(pgrid.x, pgrid.y, span);
             // the components that hold two marker ids go back to their seeds; their tiles are the second level's work
+            // (uf_bad2 doubles as the per-pixel "in an unresolved component" mark until the second level's tile pass clears
+            // it; the verification build checks keys over whole frames and keeps every lake)
+            uint8_t *in_bad = verify ? nullptr : uf_bad2;
             PCSEG_LAUNCH(ws_uf_label_kernel<UF_REPAIR>, lgrid, dim3(256), 0, s, (const int *)frame_list, (const int *)uf_parent, out,
-                         (const uint8_t *)nullptr, uf_bad1, markers, mask, flags, active, npx, W, tilesX, tilesY);
+                         (const uint8_t *)nullptr, uf_bad1, markers, mask, flags, active, npx, W, tilesX, tilesY, in_bad);
             PCSEG_CHECK_LAUNCH();
             if (verify) {
                 // whole flagged frames, so that the explicit per-pixel check of the second level sees valid keys everywhere
@@ -1838,13 +1853,14 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             uint8_t *din = dirtyA, *dout = dirtyB;
             for (int round = 0; round < WS_K2_GRID_ROUNDS; ++round) {
                 PCSEG_LAUNCH(ws_k2_relax_kernel, tgrid, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
-                             (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, H, W, tilesX, tilesY);
+                             (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, H, W, tilesX, tilesY,
+                             (const uint8_t *)in_bad);
                 PCSEG_CHECK_LAUNCH();
                 uint8_t *t = din; din = dout; dout = t;
             }
             PCSEG_LAUNCH(ws_k2_relax_tail_kernel, dim3(B), dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
                          (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, changed + 6, flags2, H, W, tilesX, tilesY,
-                         max_rounds);
+                         max_rounds, (const uint8_t *)in_bad);
             PCSEG_CHECK_LAUNCH();
             PCSEG_LAUNCH(ws_pack_kernel, lgrid, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)L, (const unsigned *)K2,
                          (const int *)flags, (const uint8_t *)active_tiles, K64, npx, W, tilesX, tilesY);

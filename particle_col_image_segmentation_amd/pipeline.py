@@ -444,11 +444,10 @@ class FramePipeline:
         _, markers, n_markers = ops.local_maxima(d2, want_mask=False)
         ws_labels, tie_flags = ops.watershed(bm, markers, mask, mode=self.watershed_mode)
         res.update(mask=mask, markers=markers, n_markers=n_markers, ws_labels=ws_labels, tie_flags=tie_flags)
-        # ---- the refined ROIs' tables: initialised here, filled (integer columns and isotope sums) by _sums_stage
-        if W % 4 == 0:
-            ws_stats, ws_sums, ws_overflow = ops.region_init(n_markers, cap, C, (B, H, W), stack.device)
-        else:
-            ws_stats, _, ws_sums, ws_overflow = ops.region_reduce(ws_labels, n_markers, cap=cap, zero_sums=C)
+        # ---- area / centroid sums of the refined ROIs (plane-free pass); their isotope sums: _sums_stage.  (The fused pass can
+        # take the integer columns along -- region_sums2(stats_b=...) -- but the refined ROIs are small, every lane ends a
+        # run or two per 32-row block, and eight 64-bit LDS atomics per run end cost more there (614 us against 407 + 191).)
+        ws_stats, _, ws_sums, ws_overflow = ops.region_reduce(ws_labels, n_markers, cap=cap, zero_sums=C)
         res.update(ws_stats=ws_stats, ws_sums=ws_sums, ws_overflow=ws_overflow)
 
     def _sums_stage(self, stack, res):
@@ -460,8 +459,7 @@ class FramePipeline:
             cell_bits |= 1 << int(v)
         B, C, H, W = stack.shape
         if W % 4 == 0:
-            ops.region_sums2(res["labels"], res["denoised"], cell_bits, res["cc_sums"], res["ws_labels"], res["ws_sums"], stack,
-                             stats_b=res["ws_stats"], overflow_b=res["ws_overflow"])
+            ops.region_sums2(res["labels"], res["denoised"], cell_bits, res["cc_sums"], res["ws_labels"], res["ws_sums"], stack)
             return
         # ragged widths: the per-image kernels (their plane pass adds nothing to the already counted integer columns'
         # cost worth a special path)
