@@ -262,12 +262,23 @@ __global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict
         unsigned best0 = gr[c], best1 = two ? gr[c + 1] : 0u;
         for (int k = 1; k <= kmax && (unsigned)(k * k) < max(best0, best1); k += 4) {
             if (c + 1 - k < 0 && c + k >= W) break;
-            // columns c-k-3 .. c-k+1 on the left, c+k .. c+k+4 on the right
+            // columns c-k-3 .. c-k+1 on the left, c+k .. c+k+4 on the right.  Away from the row's ends (almost every trip)
+            // the ten reads are two base addresses plus constant offsets; only the trips that would run over an end clamp
+            // their indices one by one (ten clamps a trip were a fifth of the loop's instructions)
             unsigned gl[5], gq[5];
+            if (c - k - 3 >= -1 && c + k + 4 <= W) {
+                const unsigned *pl = gr + (c - k + 1), *pr = gr + (c + k);
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                gl[t] = gr[max(c - k + 1 - t, -1)];
-                gq[t] = gr[min(c + k + t, W)];
+                for (int t = 0; t < 5; ++t) {
+                    gl[t] = pl[-t];
+                    gq[t] = pr[t];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    gl[t] = gr[max(c - k + 1 - t, -1)];
+                    gq[t] = gr[min(c + k + t, W)];
+                }
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {

@@ -1674,9 +1674,10 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
 
 // grid rounds enqueued before the per-frame tail kernels take over (see ws_relax_tail_kernel): the benchmark batch needs
 // 10 relaxation rounds; a round without marks costs a few microseconds.  The second level sees a few dozen tiles of a
-// few frames (benchmark batch: 31 tiles in 7 frames): two grid rounds, the per-frame tail kernel takes whatever is left
+// few frames (benchmark batch: 31 tiles in 7 frames; rounds of 127 / 60 / 25 / 18 us -- the first is one winding lake's
+// fixed point); with two grid rounds the per-frame tail kernel walks the rest one tile at a time (177 us against 43)
 #ifndef PCSEG_WS_K2_ROUNDS
-#define PCSEG_WS_K2_ROUNDS 2
+#define PCSEG_WS_K2_ROUNDS 4
 #endif
 constexpr int WS_GRID_ROUNDS = 12, WS_K2_GRID_ROUNDS = PCSEG_WS_K2_ROUNDS;
 

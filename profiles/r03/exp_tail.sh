@@ -6,7 +6,7 @@ mkdir -p $OUT
 Q="--no-cpu-baseline --secondary-batch 0 --batch64-frames 0 --no-end-to-end"
 cd $GRAFT_REPO_ROOT
 for steps in 20 80; do
-  for mode in "--eager --lanes 8" "--eager --lanes 4" "--eager --lanes 6" "--lanes 2" "--lanes 1"; do
+  for mode in "--eager --lanes 8" "--eager --lanes 4" "--eager --lanes 6" "--graph --lanes 2" "--graph --lanes 1"; do
     tag=$(echo "$mode" | tr -d ' -')
     timeout -k 10 200 python bench.py $mode --steps $steps $Q > $OUT/${tag}_k$steps.json 2> $OUT/${tag}_k$steps.err
   done
