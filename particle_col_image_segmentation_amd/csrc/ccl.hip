@@ -735,6 +735,12 @@ __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__res
         }
     }
     __syncthreads();
+    // A pixel is a candidate when none of its 8 neighbours is higher, i.e. when the maximum of the eight does not exceed it:
+    // three v_max3 and one compare instead of eight compares and their ands (the kernel is VALU-bound: 13 % VALU-active per
+    // wave at eight waves per SIMD).  "The frame is not constant" (a constant image has no maxima, extrema.py:388-391) used to
+    // be collected from the same eight neighbours; on a connected grid it is the same as "some pixel differs from the frame's
+    // first pixel": one compare per pixel.
+    const int first_value = img[fbase];
     bool any_differs = false;
     for (int t = threadIdx.x; t < LM_CH * LM_CW; t += 256) {
         const int lr = t / LM_CW, lc = t % LM_CW;  // ring coordinates: image pixel (r0 + lr - 1, c0 + lc - 1)
@@ -743,18 +749,10 @@ __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__res
         const int v = tile[i];
         uint8_t state = 2;
         if (r >= 0 && r < H && c >= 0 && c < W) {
-            bool is_cand = true, differs = false;
-#pragma unroll
-            for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-                for (int dc = -1; dc <= 1; ++dc) {
-                    if (dr == 0 && dc == 0) continue;
-                    const int q = tile[i + dr * LM_SW + dc];
-                    is_cand = is_cand && (q <= v);
-                    differs = differs || (q != v && q != OUTSIDE);
-                }
-            state = is_cand ? 1 : 0;
-            if (lr >= 1 && lr <= LM_TH && lc >= 1 && lc <= LM_TW) any_differs = any_differs || differs;
+            const int *up = tile + i - LM_SW, *dn = tile + i + LM_SW;
+            const int m = max(max(max(up[-1], up[0]), max(up[1], tile[i - 1])), max(max(tile[i + 1], dn[-1]), max(dn[0], dn[1])));
+            state = m <= v ? 1 : 0;  // (OUTSIDE = INT_MIN is never higher)
+            any_differs = any_differs || v != first_value;
         }
         cand[t] = state;
     }
