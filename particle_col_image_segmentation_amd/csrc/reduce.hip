@@ -277,14 +277,8 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
                 }
             }
         };
-        fetch(r0);
-        for (int r = r0; r <= r1; ++r) {
-            const int4 l4 = l4n;
-            const unsigned want = wantn;
-            float4 v[NC > 0 ? NC : 1];
-#pragma unroll
-            for (int k = 0; k < (NC > 0 ? NC : 1); ++k) v[k] = vn[k];
-            fetch(r + 1);
+        // one row of the walk (r == r1: the flush after the last row, with an all-zero label quad)
+        auto step = [&](const int r, const int4 l4, const unsigned want, const float4 *v) {
             const int ll[4] = {l4.x, l4.y, l4.z, l4.w};
             if (r == r1) {
                 // end of the block: the four columns of a lane usually sit in the same region; folding them first
@@ -333,14 +327,14 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
                     if (lane_id() == 0)
                         region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, l0, v_area, v_srow, v_scol, v_rmin, v_rmax, v_cmin, v_cmax,
                                           v_first, acc[0]);
-                    break;
+                    return;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (cur[j] > 0)
                         region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, cur[j], area[j], srow[j], scol[j], rmin[j], rmax1[j],
                                           cmin[j], cmax[j], first[j], acc[j]);
-                break;
+                return;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -366,6 +360,35 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
                         }
                     }
                 }
+            }
+                };
+        if constexpr (NC == 0) {
+            // plane-free walk: nothing but one 16-byte load per row, so the loads of EIGHT rows are kept in flight (with one
+            // row of look-ahead a 32-row walk was 32 memory latencies back to back: 190 us for 4 bytes per pixel)
+            const int4 zero4 = make_int4(0, 0, 0, 0);
+            int4 ring[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ring[i] = r0 + i < r1 ? *reinterpret_cast<const int4 *>(lab + (int64_t)(r0 + i) * W + c) : zero4;
+            // (one copy of the row body: the ring is rotated through registers, 28 moves a row, instead of unrolling the walk
+            // eight times -- that was 12 k instructions, more than the instruction cache holds)
+#pragma unroll 1
+            for (int r = r0; r <= r1; ++r) {
+                const int4 l4 = ring[0];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) ring[i] = ring[i + 1];
+                ring[7] = r + 8 < r1 ? *reinterpret_cast<const int4 *>(lab + (int64_t)(r + 8) * W + c) : zero4;
+                step(r, l4, 0xFu, nullptr);
+            }
+        } else {
+            fetch(r0);
+            for (int r = r0; r <= r1; ++r) {
+                const int4 l4 = l4n;
+                const unsigned want = wantn;
+                float4 v[NC > 0 ? NC : 1];
+#pragma unroll
+                for (int k = 0; k < (NC > 0 ? NC : 1); ++k) v[k] = vn[k];
+                fetch(r + 1);
+                step(r, l4, want, v);
             }
         }
     }
