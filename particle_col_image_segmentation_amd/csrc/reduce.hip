@@ -12,6 +12,7 @@
 namespace pcseg {
 
 constexpr int RED_SLOTS = 256;
+constexpr int RED_PROBES = 8;  // slots a label may take in a block's LDS table before it goes to global atomics
 constexpr int RED_MAXC = 8;
 constexpr int RED_ROWS = 16;  // rows per block
 
@@ -171,8 +172,16 @@ __device__ __forceinline__ void region_commit(const RegionSlots &ls, long long *
         if (overflow) overflow[b] = 1;
         return;
     }
-    const int slot = l & (RED_SLOTS - 1);
+    // the label's slot of the block's LDS table: its home slot or one of the next few (linear probing).  A 32-row band of a
+    // frame holds a hundred labels or so; direct mapping sent a third of the commits past the table to eight scattered
+    // 64-bit global atomics each, the slowest access the chip has
+    int slot = l & (RED_SLOTS - 1);
     int tag = atomicCAS(&ls.tags[slot], 0, l);
+#pragma unroll 1
+    for (int probe = 1; probe < RED_PROBES && tag != 0 && tag != l; ++probe) {
+        slot = (slot + 1) & (RED_SLOTS - 1);
+        tag = atomicCAS(&ls.tags[slot], 0, l);
+    }
     if (tag == 0 || tag == l) {
         atomicAdd((unsigned long long *)&ls.lstat[slot][0], (unsigned long long)s_area);
         atomicAdd((unsigned long long *)&ls.lstat[slot][1], (unsigned long long)s_r);
@@ -362,34 +371,17 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
                 }
             }
                 };
-        if constexpr (NC == 0) {
-            // plane-free walk: nothing but one 16-byte load per row, so the loads of EIGHT rows are kept in flight (with one
-            // row of look-ahead a 32-row walk was 32 memory latencies back to back: 190 us for 4 bytes per pixel)
-            const int4 zero4 = make_int4(0, 0, 0, 0);
-            int4 ring[8];
+        // (an eight-row load look-ahead for the plane-free instantiation was measured: 225 us against 202 -- the walk is not
+        // waiting for its loads)
+        fetch(r0);
+        for (int r = r0; r <= r1; ++r) {
+            const int4 l4 = l4n;
+            const unsigned want = wantn;
+            float4 v[NC > 0 ? NC : 1];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ring[i] = r0 + i < r1 ? *reinterpret_cast<const int4 *>(lab + (int64_t)(r0 + i) * W + c) : zero4;
-            // (one copy of the row body: the ring is rotated through registers, 28 moves a row, instead of unrolling the walk
-            // eight times -- that was 12 k instructions, more than the instruction cache holds)
-#pragma unroll 1
-            for (int r = r0; r <= r1; ++r) {
-                const int4 l4 = ring[0];
-#pragma unroll
-                for (int i = 0; i < 7; ++i) ring[i] = ring[i + 1];
-                ring[7] = r + 8 < r1 ? *reinterpret_cast<const int4 *>(lab + (int64_t)(r + 8) * W + c) : zero4;
-                step(r, l4, 0xFu, nullptr);
-            }
-        } else {
-            fetch(r0);
-            for (int r = r0; r <= r1; ++r) {
-                const int4 l4 = l4n;
-                const unsigned want = wantn;
-                float4 v[NC > 0 ? NC : 1];
-#pragma unroll
-                for (int k = 0; k < (NC > 0 ? NC : 1); ++k) v[k] = vn[k];
-                fetch(r + 1);
-                step(r, l4, want, v);
-            }
+            for (int k = 0; k < (NC > 0 ? NC : 1); ++k) v[k] = vn[k];
+            fetch(r + 1);
+            step(r, l4, want, v);
         }
     }
     __syncthreads();
@@ -429,8 +421,13 @@ __device__ __forceinline__ void sums_commit(const SumSlots &ls, double *gsum, in
 #pragma unroll
     for (int k = 0; k < NC; ++k) any = any || acc[k] != 0.0;
     if (!any) return;  // (regions outside the class selection, runs of zero-valued planes)
-    const int slot = l & (RED_SLOTS - 1);
-    const int tag = atomicCAS(&ls.tags[slot], 0, l);
+    int slot = l & (RED_SLOTS - 1);
+    int tag = atomicCAS(&ls.tags[slot], 0, l);
+#pragma unroll 1
+    for (int probe = 1; probe < RED_PROBES && tag != 0 && tag != l; ++probe) {  // linear probing, see region_commit
+        slot = (slot + 1) & (RED_SLOTS - 1);
+        tag = atomicCAS(&ls.tags[slot], 0, l);
+    }
     if (tag == 0 || tag == l) {
 #pragma unroll
         for (int k = 0; k < NC; ++k)
