@@ -12,7 +12,6 @@
 namespace pcseg {
 
 constexpr int RED_SLOTS = 256;
-constexpr int RED_PROBES = 8;  // slots a label may take in a block's LDS table before it goes to global atomics
 constexpr int RED_MAXC = 8;
 constexpr int RED_ROWS = 16;  // rows per block
 
@@ -172,16 +171,11 @@ __device__ __forceinline__ void region_commit(const RegionSlots &ls, long long *
         if (overflow) overflow[b] = 1;
         return;
     }
-    // the label's slot of the block's LDS table: its home slot or one of the next few (linear probing).  A 32-row band of a
-    // frame holds a hundred labels or so; direct mapping sent a third of the commits past the table to eight scattered
-    // 64-bit global atomics each, the slowest access the chip has
-    int slot = l & (RED_SLOTS - 1);
-    int tag = atomicCAS(&ls.tags[slot], 0, l);
-#pragma unroll 1
-    for (int probe = 1; probe < RED_PROBES && tag != 0 && tag != l; ++probe) {
-        slot = (slot + 1) & (RED_SLOTS - 1);
-        tag = atomicCAS(&ls.tags[slot], 0, l);
-    }
+    // (direct-mapped on purpose.  Linear probing over eight slots keeps more labels in the block's LDS table, and measured
+    // SLOWER where it matters: the float64 plane sums of a colliding label then queue at an LDS float64 atomic instead of
+    // going to the memory-side one -- the fused sums pass 540 us against 407; the integer pass did not move, 197 against 202)
+    const int slot = l & (RED_SLOTS - 1);
+    const int tag = atomicCAS(&ls.tags[slot], 0, l);
     if (tag == 0 || tag == l) {
         atomicAdd((unsigned long long *)&ls.lstat[slot][0], (unsigned long long)s_area);
         atomicAdd((unsigned long long *)&ls.lstat[slot][1], (unsigned long long)s_r);
@@ -421,13 +415,8 @@ __device__ __forceinline__ void sums_commit(const SumSlots &ls, double *gsum, in
 #pragma unroll
     for (int k = 0; k < NC; ++k) any = any || acc[k] != 0.0;
     if (!any) return;  // (regions outside the class selection, runs of zero-valued planes)
-    int slot = l & (RED_SLOTS - 1);
-    int tag = atomicCAS(&ls.tags[slot], 0, l);
-#pragma unroll 1
-    for (int probe = 1; probe < RED_PROBES && tag != 0 && tag != l; ++probe) {  // linear probing, see region_commit
-        slot = (slot + 1) & (RED_SLOTS - 1);
-        tag = atomicCAS(&ls.tags[slot], 0, l);
-    }
+    const int slot = l & (RED_SLOTS - 1);
+    const int tag = atomicCAS(&ls.tags[slot], 0, l);
     if (tag == 0 || tag == l) {
 #pragma unroll
         for (int k = 0; k < NC; ++k)
