@@ -23,31 +23,31 @@ struct KeyEqU8 {
     const uint8_t *p;
     int W;
     int64_t n;
-    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + (int64_t)r * W + c]; }
+    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + rowoff(r, W) + c]; }
 };
 struct KeyNzU8 {
     const uint8_t *p;
     int W;
     int64_t n;
-    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + (int64_t)r * W + c] != 0; }
+    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + rowoff(r, W) + c] != 0; }
 };
 struct KeyZeroU8 {  // background components (fill holes)
     const uint8_t *p;
     int W;
     int64_t n;
-    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + (int64_t)r * W + c] == 0; }
+    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + rowoff(r, W) + c] == 0; }
 };
 struct KeyIsOneU8 {  // dapi == 1
     const uint8_t *p;
     int W;
     int64_t n;
-    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + (int64_t)r * W + c] == 1; }
+    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + rowoff(r, W) + c] == 1; }
 };
 struct KeyI32 {
     const int32_t *p;
     int W;
     int64_t n;
-    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + (int64_t)r * W + c]; }
+    __device__ __forceinline__ int operator()(int b, int r, int c) const { return p[b * n + rowoff(r, W) + c]; }
 };
 // candidate pixels of the local-maxima pass: one bit per pixel in a FLAT bit array over the batch (bit b * n + r * W + c),
 // key = the pixel's value where the bit is set (0 -> INT_MIN: keys must be non-zero), 0 elsewhere
@@ -59,7 +59,7 @@ struct KeyCandBits {
     int64_t n;
     __device__ __forceinline__ int operator()(int b, int r, int c) const
     {
-        const int64_t g = b * n + (int64_t)r * W + c;
+        const int64_t g = b * n + rowoff(r, W) + c;
         if (!cand_bit(bits, g)) return 0;
         const int v = img[g];
         return v == 0 ? (int)0x80000000 : v;
@@ -290,6 +290,100 @@ __global__ void __launch_bounds__(256) ccl_relabel_kernel(const int *__restrict_
     }
 }
 
+// The same pass for n % 4 == 0, RELABEL_Q quads per lane (a block covers RELABEL_Q * SCAN_PIX pixels, quad q of a lane
+// sits q * SCAN_PIX further on, so every access is still a coalesced 16 bytes per lane).  The pass is a chain of dependent
+// gathers -- parent quad, one or two steps to the root, the root's rank code, its block offset -- and a lane that walks
+// one chain at a time waits a full memory latency at each step (91 % of the kernel's wave cycles were waits).  Here the
+// chains of a lane's RELABEL_Q quads advance in lockstep, so each step has RELABEL_Q independent loads in flight.  A quad's
+// chain belongs to its first foreground pixel; the other three almost always carry the same parent entry and take its
+// answer, one that does not walks on its own afterwards.
+constexpr int RELABEL_Q = 4;
+
+template <typename Pred>
+__device__ __forceinline__ int relabel_decode(const int *par, int *lab, const int *blockoff, const Pred &pred, int b, int64_t n, int nblk,
+                                              int p, bool chase)
+{
+    if (chase) {
+        int q;
+        while ((q = par[p]) != p) p = q;
+    }
+    if (!pred((int64_t)b * n + p)) return 0;
+    int v = __hip_atomic_load(lab + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // rank code or final label
+    if (v < 0) v = blockoff[b * nblk + p / SCAN_PIX] - v;
+    return v;
+}
+
+template <typename Pred>
+__global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
+                                                                 Pred pred, int64_t n, int nblk, bool chase)
+{
+    const int b = blockIdx.y;
+    const int *par = parent + (int64_t)b * n;
+    int *lab = labels + (int64_t)b * n;
+    const int64_t i0 = (int64_t)blockIdx.x * (SCAN_PIX * RELABEL_Q) + threadIdx.x * 4;
+    int4 pq[RELABEL_Q];
+#pragma unroll
+    for (int q = 0; q < RELABEL_Q; ++q) {
+        const int64_t i = i0 + (int64_t)q * SCAN_PIX;
+        pq[q] = i < n ? *reinterpret_cast<const int4 *>(par + i) : make_int4(-1, -1, -1, -1);
+    }
+    // neighbouring lanes mostly carry the same entry too: only the first lane of each run of equal entries walks (a gather
+    // costs the texture addresser by its active lanes), the others take its answer with one cross-lane read
+    int lead[RELABEL_Q], root[RELABEL_Q], val[RELABEL_Q], head_lane[RELABEL_Q];
+    const int lane = lane_id();
+#pragma unroll
+    for (int q = 0; q < RELABEL_Q; ++q) {
+        lead[q] = pq[q].x >= 0 ? pq[q].x : (pq[q].y >= 0 ? pq[q].y : (pq[q].z >= 0 ? pq[q].z : pq[q].w));
+        const int left = __shfl_up(lead[q], 1);
+        const bool head = lane == 0 || lead[q] != left;
+        const unsigned long long heads = __ballot(head);
+        head_lane[q] = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
+        root[q] = head ? lead[q] : -1;
+    }
+    if (chase) {
+        bool more = true;
+        while (more) {
+            int nx[RELABEL_Q];
+#pragma unroll
+            for (int q = 0; q < RELABEL_Q; ++q) nx[q] = root[q] >= 0 ? par[root[q]] : -1;
+            more = false;
+#pragma unroll
+            for (int q = 0; q < RELABEL_Q; ++q) {
+                more = more || nx[q] != root[q];
+                root[q] = nx[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RELABEL_Q; ++q) {
+        val[q] = 0;
+        if (root[q] >= 0 && pred((int64_t)b * n + root[q]))
+            val[q] = __hip_atomic_load(lab + root[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    int off[RELABEL_Q];
+#pragma unroll
+    for (int q = 0; q < RELABEL_Q; ++q) off[q] = val[q] < 0 ? blockoff[b * nblk + root[q] / SCAN_PIX] : 0;
+#pragma unroll
+    for (int q = 0; q < RELABEL_Q; ++q) {
+        if (val[q] < 0) val[q] = off[q] - val[q];
+        val[q] = __shfl(val[q], head_lane[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < RELABEL_Q; ++q) {
+        const int64_t i = i0 + (int64_t)q * SCAN_PIX;
+        if (i >= n) continue;
+        const int pv[4] = {pq[q].x, pq[q].y, pq[q].z, pq[q].w};
+        int out[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            out[j] = 0;
+            if (pv[j] < 0) continue;
+            out[j] = pv[j] == lead[q] ? val[q] : relabel_decode(par, lab, blockoff, pred, b, n, nblk, pv[j], chase);
+        }
+        *reinterpret_cast<int4 *>(lab + i) = make_int4(out[0], out[1], out[2], out[3]);
+    }
+}
+
 // ---- host-side drivers ---------------------------------------------------
 struct CclWs {
     int *parent;
@@ -344,8 +438,14 @@ static int ccl_compact(int *parent, int *blockcount, int nblk, int *labels, int 
     PCSEG_CHECK_LAUNCH();
     PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, blockcount, counts, nblk);
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH((ccl_relabel_kernel<Pred>), grid, dim3(256), 0, s, (const int *)parent, labels, (const int *)blockcount, pred, n, nblk,
-                 flatten);
+    if ((n & 3) == 0 && (((uintptr_t)parent | (uintptr_t)labels) & 15) == 0) {
+        const dim3 qgrid((unsigned)((n + SCAN_PIX * RELABEL_Q - 1) / (SCAN_PIX * RELABEL_Q)), B);
+        PCSEG_LAUNCH((ccl_relabel_quads_kernel<Pred>), qgrid, dim3(256), 0, s, (const int *)parent, labels, (const int *)blockcount, pred, n,
+                     nblk, flatten);
+    } else {
+        PCSEG_LAUNCH((ccl_relabel_kernel<Pred>), grid, dim3(256), 0, s, (const int *)parent, labels, (const int *)blockcount, pred, n, nblk,
+                     flatten);
+    }
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }
@@ -418,7 +518,7 @@ __global__ void __launch_bounds__(256) set_bits_kernel(const uint8_t *__restrict
     for (int j = 0; j < 32; ++j) {
         int r = ch * 32 + j;
         if (r < H) {
-            unsigned v = src[(int64_t)r * W + c];
+            unsigned v = src[rowoff(r, W) + c];
             if (v < 64 && ((value_bits >> v) & 1ull)) word |= 1u << j;
         }
     }
@@ -438,7 +538,7 @@ __global__ void __launch_bounds__(256) set_bits4_kernel(const uint8_t *__restric
     for (int j = 0; j < 32; ++j) {
         const int r = ch * 32 + j;
         if (r < H) {
-            const unsigned v = *reinterpret_cast<const unsigned *>(src + (int64_t)r * W);
+            const unsigned v = *reinterpret_cast<const unsigned *>(src + rowoff(r, W));
             const unsigned a = v & 255u, bb = (v >> 8) & 255u, cc = (v >> 16) & 255u, d = v >> 24;
             if (a < 64 && ((value_bits >> a) & 1ull)) w0 |= 1u << j;
             if (bb < 64 && ((value_bits >> bb) & 1ull)) w1 |= 1u << j;
@@ -472,7 +572,7 @@ __global__ void __launch_bounds__(256) set_bits4_multi_kernel(const uint8_t *__r
     for (int j = 0; j < 32; ++j) {
         const int r = ch * 32 + j;
         if (r < H) {
-            const unsigned v = *reinterpret_cast<const unsigned *>(src + (int64_t)r * W);
+            const unsigned v = *reinterpret_cast<const unsigned *>(src + rowoff(r, W));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned a = (v >> (8 * q)) & 255u;
@@ -507,10 +607,10 @@ __global__ void __launch_bounds__(256) dilate_bits_kernel(const unsigned *__rest
         for (int dx = -half; dx <= half; ++dx) {
             int cc = c + dx;
             if (cc < 0 || cc >= W) continue;
-            cur |= base[(int64_t)ch * W + cc];
+            cur |= base[rowoff(ch, W) + cc];
             if (dy > 0) {
-                if (ch > 0) prev |= base[(int64_t)(ch - 1) * W + cc];
-                if (ch + 1 < nch) next |= base[(int64_t)(ch + 1) * W + cc];
+                if (ch > 0) prev |= base[rowoff((ch - 1), W) + cc];
+                if (ch + 1 < nch) next |= base[rowoff((ch + 1), W) + cc];
             }
         }
         if (dy == 0) acc |= cur;
@@ -623,25 +723,25 @@ __global__ void __launch_bounds__(256) bitrun_border_kernel(const unsigned *__re
     const bool edge_col = col == 0 || col == BR_TW - 1;
     if (!tile_left && !tile_top && !(edge_col && ch > 0)) return;
     const unsigned *wb = bits + (int64_t)b * nch * W;
-    const unsigned w = wb[(int64_t)ch * W + c];
+    const unsigned w = wb[rowoff(ch, W) + c];
     if (w == 0) return;
     int *par = parent + (int64_t)b * H * W;
     const int row0 = ch * 32;
     if (tile_left)
-        bitrun_left_links(w, wb[(int64_t)ch * W + c - 1], [&](int a, int st) { unite_glb(par, (row0 + a) * W + c, (row0 + st) * W + c - 1); });
+        bitrun_left_links(w, wb[rowoff(ch, W) + c - 1], [&](int a, int st) { unite_glb(par, (row0 + a) * W + c, (row0 + st) * W + c - 1); });
     if ((w & 1u) && ch > 0) {
         const int node = row0 * W + c;
-        const unsigned wu = wb[(int64_t)(ch - 1) * W + c];
+        const unsigned wu = wb[rowoff((ch - 1), W) + c];
         if (wu >> 31) {
             if (tile_top) unite_glb(par, node, (row0 - 32 + bitrun_start(wu, 31)) * W + c);
         } else {
             // diagonals: made in LDS unless the word above is in another tile row, or the neighbour column in another tile
             if (c > 0 && (tile_top || col == 0)) {
-                const unsigned wd = wb[(int64_t)(ch - 1) * W + c - 1];
+                const unsigned wd = wb[rowoff((ch - 1), W) + c - 1];
                 if (wd >> 31) unite_glb(par, node, (row0 - 32 + bitrun_start(wd, 31)) * W + c - 1);
             }
             if (c + 1 < W && (tile_top || col == BR_TW - 1)) {
-                const unsigned wd = wb[(int64_t)(ch - 1) * W + c + 1];
+                const unsigned wd = wb[rowoff((ch - 1), W) + c + 1];
                 if (wd >> 31) unite_glb(par, node, (row0 - 32 + bitrun_start(wd, 31)) * W + c + 1);
             }
         }
@@ -660,7 +760,7 @@ __global__ void __launch_bounds__(256) border_flag_kernel(const int *__restrict_
     else if (t < 2 * W + 2 * H) { r = t - 2 * W - H; c = W - 1; }
     else return;
     int64_t fbase = (int64_t)blockIdx.y * H * W;
-    int p = parent[fbase + (int64_t)r * W + c];
+    int p = parent[fbase + rowoff(r, W) + c];
     if (p >= 0) flag[fbase + p] = 1;
 }
 
@@ -725,7 +825,7 @@ __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__res
         for (int t = 0; t < TRIPS; ++t) {
             const int i = min((int)threadIdx.x + 256 * t, LM_SH * LM_SW - 1);
             const int r = r0 + i / LM_SW - 2, c = c0 + i % LM_SW - 2;
-            tv[t] = img[fbase + (int64_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)];
+            tv[t] = img[fbase + rowoff(min(max(r, 0), H - 1), W) + min(max(c, 0), W - 1)];
         }
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
@@ -777,15 +877,15 @@ __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__res
             }
             // key must be non-zero for candidates and equal exactly when the values are equal (values > INT_MIN)
             k = is_cand ? (v == 0 ? (int)0x80000000 : v) : 0;
-            if (is_cand) bad[fbase + (int64_t)r * W + c] = touches ? 1 : 0;
-            else if (markers) markers[fbase + (int64_t)r * W + c] = 0;
+            if (is_cand) bad[fbase + rowoff(r, W) + c] = touches ? 1 : 0;
+            else if (markers) markers[fbase + rowoff(r, W) + c] = 0;
         }
         key[t] = k;
         // a wave covers one 64-pixel tile row per trip: its ballot is the row's candidate bits, 64 consecutive bits of the
         // flat array (they straddle two words unless the row starts on a word boundary; the array is zeroed by the caller)
         const unsigned long long rowbits = __ballot(k != 0);
         if (lane_id() == 0 && r < H && rowbits) {
-            const int64_t g = fbase + (int64_t)r * W + c0;
+            const int64_t g = fbase + rowoff(r, W) + c0;
             const int sh = (int)(g & 63);
             atomicOr(cbits + (g >> 6), rowbits << sh);
             if (sh) atomicOr(cbits + (g >> 6) + 1, rowbits >> (64 - sh));
@@ -799,7 +899,7 @@ __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__res
         const int r = r0 + i / CCL_TW, c = c0 + i % CCL_TW;
         if (r >= H || c >= W || key[i] == 0) continue;
         const int root = find_lds(par, i);
-        parent[fbase + (int64_t)r * W + c] = (r0 + root / CCL_TW) * W + c0 + root % CCL_TW;
+        parent[fbase + rowoff(r, W) + c] = (r0 + root / CCL_TW) * W + c0 + root % CCL_TW;
     }
 }
 

@@ -83,6 +83,12 @@ struct Carver {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
+// row * W as a FULL-RATE 24-bit multiply, widened afterwards: rows, word rows and widths are below 2^15 (check_shape) and a
+// frame has fewer than 2^30 pixels, so the product fits 32 bits.  Written as (int64_t)r * W the compiler emits
+// v_mad_u64_u32 -- a quarter-rate instruction -- for every pixel address of the tile kernels (87 of them in the union-find
+// tile pass, whose VALU pipe is the bottleneck).
+__device__ __forceinline__ int64_t rowoff(int r, int W) { return (int64_t)__mul24(r, W); }
+
 // Inclusive prefix maximum / minimum over the 64 lanes of a wave with DPP moves only (no LDS round trip per step, which
 // is what __shfl_up costs: ds_bpermute + a wait): four shifts inside the 16-lane rows, then lane 15 of rows 0 and 2 is
 // broadcast into rows 1 and 3, then lane 31 into rows 2 and 3.  Lanes without a source keep `ident` (bound_ctrl off).

@@ -70,15 +70,15 @@ __global__ void __launch_bounds__(256) edt_bits_kernel(Fg fg, unsigned *__restri
     if (r0 + EDT_CH <= H) {  // full word: no row test around the loads, all 32 of them in flight together
         typename Fg::raw_t raw[EDT_CH];
 #pragma unroll
-        for (int j = 0; j < EDT_CH; ++j) raw[j] = fg.raw(b, (int64_t)(r0 + j) * W + c, n);
+        for (int j = 0; j < EDT_CH; ++j) raw[j] = fg.raw(b, rowoff((r0 + j), W) + c, n);
 #pragma unroll
         for (int j = 0; j < EDT_CH; ++j)
-            if (fg.from_raw(raw[j], b, (int64_t)(r0 + j) * W + c, n)) word |= 1u << j;
+            if (fg.from_raw(raw[j], b, rowoff((r0 + j), W) + c, n)) word |= 1u << j;
     } else {
 #pragma unroll 8
         for (int j = 0; j < EDT_CH; ++j) {
             int r = r0 + j;
-            if (r < H && fg(b, (int64_t)r * W + c, n)) word |= 1u << j;
+            if (r < H && fg(b, rowoff(r, W) + c, n)) word |= 1u << j;
         }
     }
     bits[((int64_t)b * nch + ch) * W + c] = word;
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) edt_bits4_kernel(Fg fg, unsigned *__restr
     for (int j = 0; j < EDT_CH; ++j) {
         const int r = r0 + j;
         if (r < H) {
-            const unsigned v = *reinterpret_cast<const unsigned *>(src + (int64_t)r * W);
+            const unsigned v = *reinterpret_cast<const unsigned *>(src + rowoff(r, W));
             if (fg.byte(v & 255u)) w0 |= 1u << j;
             if (fg.byte((v >> 8) & 255u)) w1 |= 1u << j;
             if (fg.byte((v >> 16) & 255u)) w2 |= 1u << j;
@@ -121,20 +121,20 @@ __global__ void __launch_bounds__(256) edt_carry_kernel(const unsigned *__restri
     bool has_zero = false;
     unsigned d = G_INF;  // distance from row (r0 - 1) ... tracked as "distance of first row of the word to the zero"
     for (int ch = 0; c < W && ch < nch; ++ch) {
-        up[base + (int64_t)ch * W] = (uint16_t)d;
+        up[base + rowoff(ch, W)] = (uint16_t)d;
         int rows = min(EDT_CH, H - ch * EDT_CH);
         unsigned valid = rows == 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
-        unsigned zero = ~bits[base + (int64_t)ch * W] & valid;
+        unsigned zero = ~bits[base + rowoff(ch, W)] & valid;
         if (zero) { d = rows - (31 - __clz(zero)); has_zero = true; }  // from first row of next word to the last zero of this word
         else d = d == G_INF ? G_INF : d + rows;
     }
     if (__syncthreads_or(has_zero) && threadIdx.x == 0) any_bg[b] = 1;
     d = G_INF;
     for (int ch = nch - 1; c < W && ch >= 0; --ch) {
-        dn[base + (int64_t)ch * W] = (uint16_t)d;
+        dn[base + rowoff(ch, W)] = (uint16_t)d;
         int rows = min(EDT_CH, H - ch * EDT_CH);
         unsigned valid = rows == 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
-        unsigned zero = ~bits[base + (int64_t)ch * W] & valid;
+        unsigned zero = ~bits[base + rowoff(ch, W)] & valid;
         if (zero) d = (__ffs(zero) - 1) + 1;  // from last row of previous word to the first zero of this word
         else d = d == G_INF ? G_INF : d + rows;
     }
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict
     const int pairs_per_row = (W + 1) / 2;
     for (int idx = threadIdx.x; idx < nrows * pairs_per_row; idx += 256) {
         const int j = idx / pairs_per_row, c = (idx % pairs_per_row) * 2;
-        const int64_t gi = fbase + (int64_t)(r0 + j) * W + c;
+        const int64_t gi = fbase + rowoff((r0 + j), W) + c;
         const unsigned *gr = g2 + j * P + 1;  // gr[-1] and gr[W] are the guard cells
         const bool two = c + 1 < W;
         unsigned best0 = gr[c], best1 = two ? gr[c + 1] : 0u;
@@ -329,14 +329,18 @@ __global__ void __launch_bounds__(256) edt_reach_kernel(const unsigned *__restri
     const int64_t fbase = (int64_t)b * H * W;
     const int R2 = epi.R2();
     const unsigned gmax = (unsigned)sqrtf((float)R2) + 1;  // larger distances can never be within reach
+    // half width of the interval a zero pixel at vertical distance g reaches, for every g that can reach at all: a table
+    // in LDS (radius <= 180) instead of a square root and two fix-up compares per column and pass
+    __shared__ int reach_w[192];
+    for (unsigned gq = threadIdx.x; gq < 192; gq += 256) reach_w[gq] = (gq <= gmax && (int)(gq * gq) <= R2) ? reach_halfwidth(gq, R2) : -1;
     const bool wide = (W & 3) == 0 && ((uintptr_t)epi.out & 3) == 0 && (!Epi::kInput || ((uintptr_t)epi.input() & 3) == 0);
     // input bytes of the block (one 4-byte load per thread and row at W = 1024, all in flight together)
     if (Epi::kInput) {
-        const uint8_t *src = epi.input() + fbase + (int64_t)r0 * W;
+        const uint8_t *src = epi.input() + fbase + rowoff(r0, W);
         if (wide) {
             for (int i = threadIdx.x; i < nrows * (W / 4); i += 256) {
                 const int j = i / (W / 4), q = i % (W / 4);
-                *reinterpret_cast<unsigned *>(zb + j * W4 + 4 * q) = *reinterpret_cast<const unsigned *>(src + (int64_t)j * W + 4 * q);
+                *reinterpret_cast<unsigned *>(zb + j * W4 + 4 * q) = *reinterpret_cast<const unsigned *>(src + rowoff(j, W) + 4 * q);
             }
         } else {
             for (int i = threadIdx.x; i < nrows * W; i += 256) zb[(i / W) * W4 + i % W] = src[(int64_t)(i / W) * W + i % W];
@@ -385,7 +389,8 @@ __global__ void __launch_bounds__(256) edt_reach_kernel(const unsigned *__restri
             for (int k = 0; k < nchunks; ++k) {  // left to right: furthest column reached by the intervals that start at or before c
                 const int c = k * WAVE + lane;
                 const unsigned gv = c < W ? gr[c] : 0x7FFFu;
-                int x = (gv <= gmax && (int)(gv * gv) <= R2) ? c + reach_halfwidth(gv, R2) : -1;
+                const int wl = reach_w[min(gv, 191u)];
+                int x = wl >= 0 ? c + wl : -1;
                 x = max(wave_prefix_max(x), carry);
                 carry = wave_last_lane(x);
                 if (c < W && x >= c) gr[c] = (uint16_t)(gv | 0x8000u);
@@ -397,7 +402,8 @@ __global__ void __launch_bounds__(256) edt_reach_kernel(const unsigned *__restri
                 const int c = k * WAVE + (WAVE - 1 - lane);
                 const unsigned raw = c < W ? gr[c] : 0x7FFFu;
                 const unsigned gv = raw & 0x7FFFu;
-                int x = (gv <= gmax && (int)(gv * gv) <= R2) ? c - reach_halfwidth(gv, R2) : 0x7FFFFFFF;
+                const int wr = reach_w[min(gv, 191u)];
+                int x = wr >= 0 ? c - wr : 0x7FFFFFFF;
                 x = min(wave_prefix_min(x), carry);
                 carry = wave_last_lane(x);
                 if (c < W) zb[j * W4 + c] = epi.decide(zb[j * W4 + c], (raw & 0x8000u) != 0 || x <= c, anybg, r0 + j, c, cnt);
@@ -405,11 +411,11 @@ __global__ void __launch_bounds__(256) edt_reach_kernel(const unsigned *__restri
         }
     }
     __syncthreads();
-    uint8_t *dst = epi.out + fbase + (int64_t)r0 * W;
+    uint8_t *dst = epi.out + fbase + rowoff(r0, W);
     if (wide) {
         for (int i = threadIdx.x; i < nrows * (W / 4); i += 256) {
             const int j = i / (W / 4), q = i % (W / 4);
-            *reinterpret_cast<unsigned *>(dst + (int64_t)j * W + 4 * q) = *reinterpret_cast<const unsigned *>(zb + j * W4 + 4 * q);
+            *reinterpret_cast<unsigned *>(dst + rowoff(j, W) + 4 * q) = *reinterpret_cast<const unsigned *>(zb + j * W4 + 4 * q);
         }
     } else {
         for (int i = threadIdx.x; i < nrows * W; i += 256) dst[(int64_t)(i / W) * W + i % W] = zb[(i / W) * W4 + i % W];

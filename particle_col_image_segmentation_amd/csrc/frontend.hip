@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) classmap_median_ccl_kernel(const float *_
             int rr = r0 + lr - 2;
             rr = H >= 4 ? (rr < 0 ? -1 - rr : (rr >= H ? 2 * H - 1 - rr : rr)) : reflect_idx(rr, H);
             rr = min(max(rr, 0), H - 1);  // (rows of a ragged last tile far below the frame: any valid row, unused)
-            cls4[t] = classes4<CT>(fr, C, n, (int64_t)rr * W + c0 + 4 * q);
+            cls4[t] = classes4<CT>(fr, C, n, rowoff(rr, W) + c0 + 4 * q);
         }
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) classmap_median_ccl_kernel(const float *_
             int rr = r0 + lr - 2, cc = c0 + lc - 2;
             if (rr < 0 || rr >= H) rr = reflect_idx(rr, H);
             if (cc < 0 || cc >= W) cc = reflect_idx(cc, W);
-            hot[lr * MED_LW + lc] = 1u << (5 * class1(fr, C, n, (int64_t)rr * W + cc));
+            hot[lr * MED_LW + lc] = 1u << (5 * class1(fr, C, n, rowoff(rr, W) + cc));
         }
     } else {
         for (int i = threadIdx.x; i < MED_LH * (MED_TW + 4); i += 256) {
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) classmap_median_ccl_kernel(const float *_
             int rr = r0 + lr - 2, cc = c0 + lc - 2;
             if (rr < 0 || rr >= H) rr = reflect_idx(rr, H);
             if (cc < 0 || cc >= W) cc = reflect_idx(cc, W);
-            hot[lr * MED_LW + lc] = 1u << (5 * class1(fr, C, n, (int64_t)rr * W + cc));
+            hot[lr * MED_LW + lc] = 1u << (5 * class1(fr, C, n, rowoff(rr, W) + cc));
         }
     }
     __syncthreads();
@@ -114,9 +114,9 @@ __global__ void __launch_bounds__(256) classmap_median_ccl_kernel(const float *_
         for (int j = 0; j < 4; ++j) key[lr * CCL_TW + lc + j] = (r < H && c + j < W) ? (int)med[j] : 0;
         if (r < H && c < W) {
             if (c + 3 < W && (W & 3) == 0) {
-                *reinterpret_cast<uint32_t *>(dst + (int64_t)r * W + c) = med[0] | (med[1] << 8) | (med[2] << 16) | (med[3] << 24);
+                *reinterpret_cast<uint32_t *>(dst + rowoff(r, W) + c) = med[0] | (med[1] << 8) | (med[2] << 16) | (med[3] << 24);
             } else {
-                for (int j = 0; j < 4 && c + j < W; ++j) dst[(int64_t)r * W + c + j] = (uint8_t)med[j];
+                for (int j = 0; j < 4 && c + j < W; ++j) dst[rowoff(r, W) + c + j] = (uint8_t)med[j];
             }
         }
     }

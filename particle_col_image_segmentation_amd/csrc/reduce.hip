@@ -63,17 +63,17 @@ __global__ void __launch_bounds__(256) region_reduce_kernel(const int *__restric
         if (r >= H) break;
         const int c = (item % segs) * 64 + lane;
         const bool inb = c < W;
-        const int l = inb ? lab[(int64_t)r * W + c] : 0;
+        const int l = inb ? lab[rowoff(r, W) + c] : 0;
         float v[RED_MAXC];
         if (HAS_PLANES) {
             // sel != 0: plane sums only where the class map holds one of the selected values
             bool want = inb && l > 0;
             if (want && sel) {
-                const unsigned cv = cls[(int64_t)b * n + (int64_t)r * W + c];
+                const unsigned cv = cls[(int64_t)b * n + rowoff(r, W) + c];
                 want = cv < 64 && ((sel >> cv) & 1ull);
             }
 #pragma unroll
-            for (int k = 0; k < RED_MAXC; ++k) v[k] = (k < C && want) ? pl[(int64_t)k * n + (int64_t)r * W + c] : 0.f;
+            for (int k = 0; k < RED_MAXC; ++k) v[k] = (k < C && want) ? pl[(int64_t)k * n + rowoff(r, W) + c] : 0.f;
         }
         const int lprev = __shfl_up(l, 1);
         const bool head = (lane == 0) || (l != lprev);
@@ -155,17 +155,37 @@ __global__ void __launch_bounds__(256) region_reduce_kernel(const int *__restric
     }
 }
 
-// shared commit step of the reduce kernels: LDS slot if the label owns (or can claim) it, else global atomics
+// shared commit step of the column-run reduce kernels: LDS slot if the label owns (or can claim) it, else global atomics.
+// A block covers COL_ROWS rows x 1024 columns (32768 pixels at most) of a frame no larger than 32768 x 32768, so every
+// block-local partial -- area, row and column sums, the first raster index -- fits 32 bits: the LDS table and the lane
+// accumulators are 32-bit (full-rate ds atomics, half the LDS traffic of 64-bit ones), widened at the flush.
 struct RegionSlots {
     int *tags;
-    long long (*lstat)[8];
+    int (*lstat)[8];
     double (*lsum)[RED_MAXC];
 };
 
+__device__ __forceinline__ void region_slots_clear(int *t, int H, int W)
+{
+    t[0] = 0; t[1] = 0; t[2] = 0; t[3] = H; t[4] = W; t[5] = 0; t[6] = 0; t[7] = 0x7FFFFFFF;
+}
+
+__device__ __forceinline__ void region_slots_flush(const int *s, long long *t)
+{
+    atomicAdd((unsigned long long *)&t[0], (unsigned long long)(unsigned)s[0]);
+    atomicAdd((unsigned long long *)&t[1], (unsigned long long)(unsigned)s[1]);
+    atomicAdd((unsigned long long *)&t[2], (unsigned long long)(unsigned)s[2]);
+    atomic_min_i64(&t[3], (long long)s[3]);
+    atomic_min_i64(&t[4], (long long)s[4]);
+    atomic_max_i64(&t[5], (long long)s[5]);
+    atomic_max_i64(&t[6], (long long)s[6]);
+    atomic_min_i64(&t[7], (long long)s[7]);
+}
+
 template <int NC>
 __device__ __forceinline__ void region_commit(const RegionSlots &ls, long long *gst, double *gsum, int *overflow, int b, int cap,
-                                              int C, int l, long long s_area, long long s_r, long long s_c, long long rmin,
-                                              long long rmax1, long long c0, long long c1, long long first, const double *acc)
+                                              int C, int l, int s_area, int s_r, int s_c, int rmin, int rmax1, int c0, int c1,
+                                              int first, const double *acc)
 {
     if (l > cap) {
         if (overflow) overflow[b] = 1;
@@ -177,32 +197,42 @@ __device__ __forceinline__ void region_commit(const RegionSlots &ls, long long *
     const int slot = l & (RED_SLOTS - 1);
     const int tag = atomicCAS(&ls.tags[slot], 0, l);
     if (tag == 0 || tag == l) {
-        atomicAdd((unsigned long long *)&ls.lstat[slot][0], (unsigned long long)s_area);
-        atomicAdd((unsigned long long *)&ls.lstat[slot][1], (unsigned long long)s_r);
-        atomicAdd((unsigned long long *)&ls.lstat[slot][2], (unsigned long long)s_c);
-        atomic_min_i64(&ls.lstat[slot][3], rmin);
-        atomic_min_i64(&ls.lstat[slot][4], c0);
-        atomic_max_i64(&ls.lstat[slot][5], rmax1);
-        atomic_max_i64(&ls.lstat[slot][6], c1 + 1);
-        atomic_min_i64(&ls.lstat[slot][7], first);
+        int *t = ls.lstat[slot];
+        atomicAdd((unsigned *)&t[0], (unsigned)s_area);
+        atomicAdd((unsigned *)&t[1], (unsigned)s_r);
+        atomicAdd((unsigned *)&t[2], (unsigned)s_c);
+        atomicMin(&t[3], rmin);
+        atomicMin(&t[4], c0);
+        atomicMax(&t[5], rmax1);
+        atomicMax(&t[6], c1 + 1);
+        atomicMin(&t[7], first);
 #pragma unroll
         for (int k = 0; k < NC; ++k)
             if (k < C && acc[k] != 0.0) atomicAdd(&ls.lsum[slot][k], acc[k]);  // (regions outside the class selection sum to 0)
     } else {
         long long *t = gst + (int64_t)(l - 1) * 8;
-        atomicAdd((unsigned long long *)&t[0], (unsigned long long)s_area);
-        atomicAdd((unsigned long long *)&t[1], (unsigned long long)s_r);
-        atomicAdd((unsigned long long *)&t[2], (unsigned long long)s_c);
-        atomic_min_i64(&t[3], rmin);
-        atomic_min_i64(&t[4], c0);
-        atomic_max_i64(&t[5], rmax1);
-        atomic_max_i64(&t[6], c1 + 1);
-        atomic_min_i64(&t[7], first);
+        atomicAdd((unsigned long long *)&t[0], (unsigned long long)(unsigned)s_area);
+        atomicAdd((unsigned long long *)&t[1], (unsigned long long)(unsigned)s_r);
+        atomicAdd((unsigned long long *)&t[2], (unsigned long long)(unsigned)s_c);
+        atomic_min_i64(&t[3], (long long)rmin);
+        atomic_min_i64(&t[4], (long long)c0);
+        atomic_max_i64(&t[5], (long long)rmax1);
+        atomic_max_i64(&t[6], (long long)c1 + 1);
+        atomic_min_i64(&t[7], (long long)first);
 #pragma unroll
         for (int k = 0; k < NC; ++k)
             if (k < C && acc[k] != 0.0) atomicAdd(&gsum[(int64_t)(l - 1) * C + k], acc[k]);
     }
 }
+
+// The row walks below fetch row r + 1 before they process row r.  The compiler's wait-count pass cannot count loads across
+// the loop's back edge: left alone it puts `s_waitcnt vmcnt(0)` at the first USE of row r -- after the loads of row r + 1
+// went out -- and every step then waits a full memory latency (the plane-free pass ran at 1.3 TB/s for that reason).
+// "Using" row r's registers in an empty asm ahead of the fetch moves that wait to the top of the step, where only row
+// r's loads are outstanding.
+__device__ __forceinline__ void landed(const int4 &q) { asm volatile("" ::"v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w) : "memory"); }
+__device__ __forceinline__ void landed(const float4 &q) { asm volatile("" ::"v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w) : "memory"); }
+__device__ __forceinline__ void landed(unsigned q) { asm volatile("" ::"v"(q) : "memory"); }
 
 // Column-run variant (W % 4 == 0): a lane owns 4 adjacent columns and walks DOWN COL_ROWS rows; it accumulates the
 // vertical run of equal labels in registers (area, row sum, plane sums in float64) and commits when the label
@@ -224,7 +254,7 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
                                                                  double *__restrict__ sums, int *__restrict__ overflow)
 {
     __shared__ int tags[RED_SLOTS];
-    __shared__ long long lstat[RED_SLOTS][8];
+    __shared__ int lstat[RED_SLOTS][8];
     __shared__ double lsum[NC > 0 ? RED_SLOTS : 1][RED_MAXC];
     const int b = blockIdx.z;
     const int64_t n = (int64_t)H * W;
@@ -234,8 +264,7 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
     double *gsum = NC > 0 ? sums + (int64_t)b * cap * C : nullptr;
     for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
         tags[i] = 0;
-        lstat[i][0] = 0; lstat[i][1] = 0; lstat[i][2] = 0; lstat[i][3] = H; lstat[i][4] = W; lstat[i][5] = 0; lstat[i][6] = 0;
-        lstat[i][7] = 0x7FFFFFFFFFFFFFFFLL;
+        region_slots_clear(lstat[i], H, W);
         if (NC > 0)
             for (int k = 0; k < RED_MAXC; ++k) lsum[i][k] = 0.0;
     }
@@ -245,7 +274,7 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
     const int r0 = blockIdx.y * COL_ROWS, r1 = min(H, r0 + COL_ROWS);
     if (c < W) {
         int cur[4] = {0, 0, 0, 0}, start[4] = {0, 0, 0, 0};
-        long long area[4] = {0, 0, 0, 0}, srow[4] = {0, 0, 0, 0};
+        int area[4] = {0, 0, 0, 0}, srow[4] = {0, 0, 0, 0};
         double acc[4][NC > 0 ? NC : 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -259,13 +288,14 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
         // group without such a pixel are not even read (for class-map components only cell regions need sums, and they
         // are a small part of a frame)
         unsigned wantn = 0xF;
+        int64_t at = rowoff(r0, W) + c;  // (fetch() walks the rows in order)
         auto fetch = [&](int r) {
             l4n = make_int4(0, 0, 0, 0);
             if (r < r1) {
-                l4n = *reinterpret_cast<const int4 *>(lab + (int64_t)r * W + c);
+                l4n = *reinterpret_cast<const int4 *>(lab + at);
                 if (NC > 0) {
                     if (sel) {
-                        const unsigned cw = *reinterpret_cast<const unsigned *>(cls + (int64_t)b * n + (int64_t)r * W + c);
+                        const unsigned cw = *reinterpret_cast<const unsigned *>(cls + (int64_t)b * n + at);
                         wantn = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -275,9 +305,10 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
                     }
 #pragma unroll
                     for (int k = 0; k < NC; ++k)
-                        vn[k] = (k < C && wantn) ? *reinterpret_cast<const float4 *>(pl + (int64_t)k * n + (int64_t)r * W + c)
+                        vn[k] = (k < C && wantn) ? *reinterpret_cast<const float4 *>(pl + (int64_t)k * n + at)
                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+                at += W;
             }
         };
         // one row of the walk (r == r1: the flush after the last row, with an all-zero label quad)
@@ -286,14 +317,14 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
             if (r == r1) {
                 // end of the block: the four columns of a lane usually sit in the same region; folding them first
                 // quarters the number of same-slot LDS atomics the whole block fires at once
-                long long scol[4], rmin[4], rmax1[4], cmin[4], cmax[4], first[4];
+                int scol[4], rmin[4], rmax1[4], cmin[4], cmax[4], first[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    scol[j] = (long long)(c + j) * area[j];
+                    scol[j] = __mul24(c + j, area[j]);
                     rmin[j] = start[j];
                     rmax1[j] = start[j] + area[j];
                     cmin[j] = cmax[j] = c + j;
-                    first[j] = (long long)start[j] * W + c + j;
+                    first[j] = __mul24(start[j], W) + c + j;
                 }
 #pragma unroll
                 for (int j = 1; j < 4; ++j)
@@ -313,8 +344,8 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
                 const int l0 = __builtin_amdgcn_readfirstlane(cur[0]);
                 // (only a fully active wave: a shuffle from a lane beyond the frame's width would read nothing defined)
                 if (__ballot(true) == ~0ull && __all(cur[0] == l0 && l0 > 0 && cur[1] == 0 && cur[2] == 0 && cur[3] == 0)) {
-                    long long v_area = area[0], v_srow = srow[0], v_scol = scol[0], v_rmin = rmin[0], v_rmax = rmax1[0], v_cmin = cmin[0],
-                              v_cmax = cmax[0], v_first = first[0];
+                    int v_area = area[0], v_srow = srow[0], v_scol = scol[0], v_rmin = rmin[0], v_rmax = rmax1[0], v_cmin = cmin[0],
+                        v_cmax = cmax[0], v_first = first[0];
                     for (int off = 32; off; off >>= 1) {
                         v_area += __shfl_xor(v_area, off);
                         v_srow += __shfl_xor(v_srow, off);
@@ -343,8 +374,8 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
             for (int j = 0; j < 4; ++j) {
                 if (ll[j] != cur[j]) {
                     if (cur[j] > 0)
-                        region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, cur[j], area[j], srow[j], (long long)(c + j) * area[j],
-                                          start[j], start[j] + area[j], c + j, c + j, (long long)start[j] * W + c + j, acc[j]);
+                        region_commit<NC>(ls, gst, gsum, overflow, b, cap, C, cur[j], area[j], srow[j], __mul24(c + j, area[j]),
+                                          start[j], start[j] + area[j], c + j, c + j, __mul24(start[j], W) + c + j, acc[j]);
                     cur[j] = ll[j];
                     start[j] = r;
                     area[j] = 0;
@@ -374,6 +405,11 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
             float4 v[NC > 0 ? NC : 1];
 #pragma unroll
             for (int k = 0; k < (NC > 0 ? NC : 1); ++k) v[k] = vn[k];
+            landed(l4);
+            if (NC > 0) {
+#pragma unroll
+                for (int k = 0; k < NC; ++k) landed(v[k]);
+            }
             fetch(r + 1);
             step(r, l4, want, v);
         }
@@ -382,15 +418,7 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
     for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
         const int l = tags[i];
         if (l == 0) continue;
-        long long *t = gst + (int64_t)(l - 1) * 8;
-        atomicAdd((unsigned long long *)&t[0], (unsigned long long)lstat[i][0]);
-        atomicAdd((unsigned long long *)&t[1], (unsigned long long)lstat[i][1]);
-        atomicAdd((unsigned long long *)&t[2], (unsigned long long)lstat[i][2]);
-        atomic_min_i64(&t[3], lstat[i][3]);
-        atomic_min_i64(&t[4], lstat[i][4]);
-        atomic_max_i64(&t[5], lstat[i][5]);
-        atomic_max_i64(&t[6], lstat[i][6]);
-        atomic_min_i64(&t[7], lstat[i][7]);
+        region_slots_flush(lstat[i], gst + (int64_t)(l - 1) * 8);
         if (NC > 0)
             for (int k = 0; k < C; ++k) atomicAdd(&gsum[(int64_t)(l - 1) * C + k], lsum[i][k]);
     }
@@ -430,8 +458,12 @@ __device__ __forceinline__ void sums_commit(const SumSlots &ls, double *gsum, in
 
 // STATS_B: image B's integer columns (area, centroid sums, bounding box, first pixel) are accumulated in the same walk
 // (its runs are tracked anyway): the refined ROIs' table then needs no pass of its own.
-template <int NC, bool STATS_B>
-__global__ void __launch_bounds__(256, 2) region_sums2_col_kernel(const int *__restrict__ labels_a, const uint8_t *__restrict__ cls,
+// (five planes without image B's integer columns fit 168 registers: three blocks per CU instead of two, 409 us a launch
+// against 497)
+// EXACT: C == NC, the plane loads carry no test of C (each test is a scalar branch, and the compiler drains the load queue
+// at some of them).
+template <int NC, bool STATS_B, bool EXACT>
+__global__ void __launch_bounds__(256, (NC <= 5 && !STATS_B) ? 3 : 2) region_sums2_col_kernel(const int *__restrict__ labels_a, const uint8_t *__restrict__ cls,
                                                                   unsigned long long sel, const int *__restrict__ labels_b,
                                                                   const float *__restrict__ planes, int C, int H, int W, int cap_a,
                                                                   int cap_b, double *__restrict__ sums_a, double *__restrict__ sums_b,
@@ -439,7 +471,7 @@ __global__ void __launch_bounds__(256, 2) region_sums2_col_kernel(const int *__r
 {
     __shared__ int tags_a[RED_SLOTS], tags_b[RED_SLOTS];
     __shared__ double lsum_a[RED_SLOTS][RED_MAXC], lsum_b[RED_SLOTS][RED_MAXC];
-    __shared__ long long lstat_b[STATS_B ? RED_SLOTS : 1][8];
+    __shared__ int lstat_b[STATS_B ? RED_SLOTS : 1][8];
     const int b = blockIdx.z;
     const int64_t n = (int64_t)H * W;
     const int *la = labels_a + (int64_t)b * n, *lb = labels_b + (int64_t)b * n;
@@ -450,10 +482,7 @@ __global__ void __launch_bounds__(256, 2) region_sums2_col_kernel(const int *__r
         tags_a[i] = 0;
         tags_b[i] = 0;
         for (int k = 0; k < RED_MAXC; ++k) { lsum_a[i][k] = 0.0; lsum_b[i][k] = 0.0; }
-        if (STATS_B) {
-            lstat_b[i][0] = 0; lstat_b[i][1] = 0; lstat_b[i][2] = 0; lstat_b[i][3] = H; lstat_b[i][4] = W; lstat_b[i][5] = 0;
-            lstat_b[i][6] = 0; lstat_b[i][7] = 0x7FFFFFFFFFFFFFFFLL;
-        }
+        if (STATS_B) region_slots_clear(lstat_b[i], H, W);
     }
     __syncthreads();
     const SumSlots sa{tags_a, lsum_a}, sb{tags_b, lsum_b};
@@ -463,7 +492,7 @@ __global__ void __launch_bounds__(256, 2) region_sums2_col_kernel(const int *__r
     if (c < W) {
         int cur_a[4] = {0, 0, 0, 0}, cur_b[4] = {0, 0, 0, 0};
         int start_b[4] = {0, 0, 0, 0}, area_b[4] = {0, 0, 0, 0};
-        long long srow_b[4] = {0, 0, 0, 0};
+        int srow_b[4] = {0, 0, 0, 0};
         double acc_a[4][NC], acc_b[4][NC];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -472,35 +501,48 @@ __global__ void __launch_bounds__(256, 2) region_sums2_col_kernel(const int *__r
         // the next row's eight 16-byte loads are issued before this row is processed
         int4 a4n = make_int4(0, 0, 0, 0), b4n = make_int4(0, 0, 0, 0);
         float4 vn[NC];
-        unsigned wantn = 0xF;
+        // (the class bytes are decoded when the row is processed, not when it is fetched: a decode here would wait for the
+        // label loads of the row ahead and undo the look-ahead)
+        // without a selection the load reads bytes of image A instead (never used): a conditional load would make the
+        // compiler wait for the previous one before it can keep its value
+        unsigned cwn = 0;
+        const uint8_t *cbytes = sel ? cls + (int64_t)b * n : reinterpret_cast<const uint8_t *>(la);
+        int64_t at = rowoff(r0, W) + c;  // (fetch() walks the rows in order)
         auto fetch = [&](int r) {
             a4n = make_int4(0, 0, 0, 0);
             b4n = make_int4(0, 0, 0, 0);
             if (r < r1) {
-                a4n = *reinterpret_cast<const int4 *>(la + (int64_t)r * W + c);
-                b4n = *reinterpret_cast<const int4 *>(lb + (int64_t)r * W + c);
-                if (sel) {
-                    const unsigned cw = *reinterpret_cast<const unsigned *>(cls + (int64_t)b * n + (int64_t)r * W + c);
-                    wantn = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const unsigned cv = (cw >> (8 * j)) & 255u;
-                        if (cv < 64 && ((sel >> cv) & 1ull)) wantn |= 1u << j;
-                    }
-                }
+                a4n = *reinterpret_cast<const int4 *>(la + at);
+                b4n = *reinterpret_cast<const int4 *>(lb + at);
+                cwn = *reinterpret_cast<const unsigned *>(cbytes + at);
 #pragma unroll
                 for (int k = 0; k < NC; ++k)
-                    vn[k] = k < C ? *reinterpret_cast<const float4 *>(pl + (int64_t)k * n + (int64_t)r * W + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    vn[k] = (EXACT || k < C) ? *reinterpret_cast<const float4 *>(pl + (int64_t)k * n + at) : make_float4(0.f, 0.f, 0.f, 0.f);
+                at += W;
             }
         };
         fetch(r0);
         for (int r = r0; r <= r1; ++r) {
             const int4 a4 = a4n, b4 = b4n;
-            const unsigned want = wantn;
+            const unsigned cw = cwn;
             float4 v[NC];
 #pragma unroll
             for (int k = 0; k < NC; ++k) v[k] = vn[k];
+            landed(a4);
+            landed(b4);
+            landed(cw);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) landed(v[k]);
             fetch(r + 1);
+            unsigned want = 0xF;
+            if (sel) {
+                want = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned cv = (cw >> (8 * j)) & 255u;
+                    if (cv < 64 && ((sel >> cv) & 1ull)) want |= 1u << j;
+                }
+            }
             const int aa[4] = {a4.x, a4.y, a4.z, a4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};  // (row r1: zeros -> every run ends)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -514,8 +556,8 @@ __global__ void __launch_bounds__(256, 2) region_sums2_col_kernel(const int *__r
                     if (STATS_B) {
                         if (cur_b[j] > 0)
                             region_commit<NC>(sbb, gst_b, gb, overflow_b, b, cap_b, C, cur_b[j], area_b[j], srow_b[j],
-                                              (long long)(c + j) * area_b[j], start_b[j], start_b[j] + area_b[j], c + j, c + j,
-                                              (long long)start_b[j] * W + c + j, acc_b[j]);
+                                              __mul24(c + j, area_b[j]), start_b[j], start_b[j] + area_b[j], c + j, c + j,
+                                              __mul24(start_b[j], W) + c + j, acc_b[j]);
                         start_b[j] = r;
                         area_b[j] = 0;
                         srow_b[j] = 0;
@@ -552,17 +594,7 @@ __global__ void __launch_bounds__(256, 2) region_sums2_col_kernel(const int *__r
         if (l2) {
             for (int k = 0; k < C; ++k)
                 if (lsum_b[i][k] != 0.0) atomicAdd(&gb[(int64_t)(l2 - 1) * C + k], lsum_b[i][k]);
-            if (STATS_B) {
-                long long *t = gst_b + (int64_t)(l2 - 1) * 8;
-                atomicAdd((unsigned long long *)&t[0], (unsigned long long)lstat_b[i][0]);
-                atomicAdd((unsigned long long *)&t[1], (unsigned long long)lstat_b[i][1]);
-                atomicAdd((unsigned long long *)&t[2], (unsigned long long)lstat_b[i][2]);
-                atomic_min_i64(&t[3], lstat_b[i][3]);
-                atomic_min_i64(&t[4], lstat_b[i][4]);
-                atomic_max_i64(&t[5], lstat_b[i][5]);
-                atomic_max_i64(&t[6], lstat_b[i][6]);
-                atomic_min_i64(&t[7], lstat_b[i][7]);
-            }
+            if (STATS_B) region_slots_flush(lstat_b[i], gst_b + (int64_t)(l2 - 1) * 8);
         }
     }
 }
@@ -1112,12 +1144,16 @@ int pcseg_region_sums2(const int32_t *labels_a, const uint8_t *cls, uint64_t sum
     const dim3 cgrid((W / 4 + 255) / 256, (H + COL_ROWS - 1) / COL_ROWS, B);
     const unsigned long long sel = sum_class_bits;
 #define PCSEG_SUMS2(NCV, ST)                                                                                                        \
-    PCSEG_LAUNCH((region_sums2_col_kernel<NCV, ST>), cgrid, dim3(256), 0, s, labels_a, cls, sel, labels_b, planes, C, H, W, cap_a, cap_b, \
+    if (C == NCV)                                                                                                                   \
+        PCSEG_LAUNCH((region_sums2_col_kernel<NCV, ST, true>), cgrid, dim3(256), 0, s, labels_a, cls, sel, labels_b, planes, C, H, W, \
+                     cap_a, cap_b, sums_a, sums_b, (long long *)stats_b, overflow_b);                                              \
+    else                                                                                                                            \
+        PCSEG_LAUNCH((region_sums2_col_kernel<NCV, ST, false>), cgrid, dim3(256), 0, s, labels_a, cls, sel, labels_b, planes, C, H, W, cap_a, cap_b, \
                  sums_a, sums_b, (long long *)stats_b, overflow_b)
-    if (C <= 5 && stats_b) PCSEG_SUMS2(5, true);
-    else if (C <= 5) PCSEG_SUMS2(5, false);
-    else if (stats_b) PCSEG_SUMS2(8, true);
-    else PCSEG_SUMS2(8, false);
+    if (C <= 5 && stats_b) { PCSEG_SUMS2(5, true); }
+    else if (C <= 5) { PCSEG_SUMS2(5, false); }
+    else if (stats_b) { PCSEG_SUMS2(8, true); }
+    else { PCSEG_SUMS2(8, false); }
 #undef PCSEG_SUMS2
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;

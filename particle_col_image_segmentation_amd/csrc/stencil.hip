@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) median5_kernel(const uint8_t *__restrict_
         int rr = r0 + lr - 2, cc = c0 + lc - 2;
         if (rr < 0 || rr >= H) rr = reflect_idx(rr, H);  // only tiles on the frame's rim pay for the modulo
         if (cc < 0 || cc >= W) cc = reflect_idx(cc, W);
-        uint8_t v = src[(int64_t)rr * W + cc];
+        uint8_t v = src[rowoff(rr, W) + cc];
         tile[lr * MED_LW + lc] = v;
         local_max = max(local_max, (int)v);
     }
@@ -146,9 +146,9 @@ __global__ void __launch_bounds__(256) median5_kernel(const uint8_t *__restrict_
             median5_hot_strip(hot, lr, lc, med);
             const int c = c0 + lc;
             if (c + 3 < W && (W & 3) == 0) {
-                *reinterpret_cast<uint32_t *>(dst + (int64_t)r * W + c) = med[0] | (med[1] << 8) | (med[2] << 16) | (med[3] << 24);
+                *reinterpret_cast<uint32_t *>(dst + rowoff(r, W) + c) = med[0] | (med[1] << 8) | (med[2] << 16) | (med[3] << 24);
             } else {
-                for (int j = 0; j < 4 && c + j < W; ++j) dst[(int64_t)r * W + c + j] = (uint8_t)med[j];
+                for (int j = 0; j < 4 && c + j < W; ++j) dst[rowoff(r, W) + c + j] = (uint8_t)med[j];
             }
         }
         return;
@@ -184,10 +184,10 @@ __global__ void __launch_bounds__(256) median5_kernel(const uint8_t *__restrict_
         }
         int c = c0 + lc;
         if (c + 3 < W && (W & 3) == 0) {
-            *reinterpret_cast<uint32_t *>(dst + (int64_t)r * W + c) =
+            *reinterpret_cast<uint32_t *>(dst + rowoff(r, W) + c) =
                 med[0] | (med[1] << 8) | (med[2] << 16) | (med[3] << 24);
         } else {
-            for (int j = 0; j < 4 && c + j < W; ++j) dst[(int64_t)r * W + c + j] = (uint8_t)med[j];
+            for (int j = 0; j < 4 && c + j < W; ++j) dst[rowoff(r, W) + c + j] = (uint8_t)med[j];
         }
     }
 }
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) morph3x3_kernel(const uint8_t *__restrict
     for (int dr = -1; dr <= 1; ++dr)
         for (int dc = -1; dc <= 1; ++dc) {
             int rr = r + dr, cc = c + dc;
-            int v = (rr < 0 || rr >= H || cc < 0 || cc >= W) ? (erode ? 1 : 0) : (src[(int64_t)rr * W + cc] != 0);
+            int v = (rr < 0 || rr >= H || cc < 0 || cc >= W) ? (erode ? 1 : 0) : (src[rowoff(rr, W) + cc] != 0);
             acc = erode ? (acc & v) : (acc | v);
         }
     out[(int64_t)blockIdx.z * H * W + (int64_t)r * W + c] = (uint8_t)acc;

@@ -67,7 +67,7 @@ __device__ __forceinline__ void ws_load_tile(T *s, const T *__restrict__ g, int 
     for (int i = threadIdx.x; i < WS_S * WS_S; i += 256) {
         int lr = i / WS_S, lc = i % WS_S;
         int r = r0 + lr - 1, c = c0 + lc - 1;
-        s[lr * WS_P + lc] = (r >= 0 && r < H && c >= 0 && c < W) ? g[(int64_t)r * W + c] : fill;
+        s[lr * WS_P + lc] = (r >= 0 && r < H && c >= 0 && c < W) ? g[rowoff(r, W) + c] : fill;
     }
 }
 
@@ -96,7 +96,7 @@ __device__ __forceinline__ void ws_store_tile(const T *s, T *__restrict__ g, int
     for (int i = threadIdx.x; i < WS_T * WS_T; i += 256) {
         int lr = i / WS_T, lc = i % WS_T;
         int r = r0 + lr, c = c0 + lc;
-        if (r < H && c < W) g[(int64_t)r * W + c] = s[(lr + 1) * WS_P + lc + 1];
+        if (r < H && c < W) g[rowoff(r, W) + c] = s[(lr + 1) * WS_P + lc + 1];
     }
 }
 
@@ -111,7 +111,7 @@ __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__res
     const int lc = e == 2 ? 1 : (e == 3 ? WS_T : j + 1);
     const int r = r0 + lr - 1, c = c0 + lc - 1;
     bool ch = false;
-    if (r < H && c < W) ch = s[lr * WS_P + lc] != g[(int64_t)r * W + c];
+    if (r < H && c < W) ch = s[lr * WS_P + lc] != g[rowoff(r, W) + c];
     if (__any(ch) && j == 0) {
         uint8_t *d = dirty_out + (int64_t)b * tilesX * tilesY;
         if (e == 0 && ty > 0) d[(ty - 1) * tilesX + tx] = 1;
@@ -406,9 +406,9 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
     const int64_t fbase = (int64_t)b * H * W;
     // (L, value) of a pixel before any relaxation
     auto initial = [&](int r, int c) -> uint2 {
-        const int64_t g = fbase + (int64_t)r * W + c;
+        const int64_t g = fbase + rowoff(r, W) + c;
         if (!in.mask[g]) return make_uint2(WS_INF, WS_INF);
-        const unsigned v = ws_key(in.img[(int64_t)b * in.frame_stride + (int64_t)r * W + c]);
+        const unsigned v = ws_key(in.img[(int64_t)b * in.frame_stride + rowoff(r, W) + c]);
         return make_uint2(in.markers[g] != 0 ? v : WS_INF, v);
     };
     if (in.vec) {
@@ -424,7 +424,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
         const int h_lr = tid >> 1, h_lc = (tid & 1) ? S - 1 : 0;
         const int h_r = r0 + h_lr - 1, h_c = c0 + h_lc - 1;
         const bool h_in = halo_thread && h_r >= 0 && h_r < H && h_c >= 0 && h_c < W;
-        const int64_t h_p = (int64_t)min(max(h_r, 0), H - 1) * W + min(max(h_c, 0), W - 1);
+        const int64_t h_p = rowoff(min(max(h_r, 0), H - 1), W) + min(max(h_c, 0), W - 1);
         if (FIRST) {
             float4 f4[TRIPS];
             int4 m4[TRIPS];
@@ -433,7 +433,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             for (int t = 0; t < TRIPS; ++t) {
                 const int idx = min(tid + NT * t, QUADS - 1);
                 const int lr = idx / QW, q = idx % QW;
-                const int64_t p = (int64_t)min(max(r0 + lr - 1, 0), H - 1) * W + min(max(c0 + 4 * q, 0), W - 4);
+                const int64_t p = rowoff(min(max(r0 + lr - 1, 0), H - 1), W) + min(max(c0 + 4 * q, 0), W - 4);
                 f4[t] = *reinterpret_cast<const float4 *>(img_f + p);
                 m4[t] = *reinterpret_cast<const int4 *>(in.markers + fbase + p);
                 k4[t] = *reinterpret_cast<const unsigned *>(in.mask + fbase + p);
@@ -460,7 +460,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
                         sLV[lr * P + 1 + 4 * q + j] = make_uint2(lab[j] != 0 ? key[j] : WS_INF, key[j]);
                     }
                     if (inside && lr >= 1 && lr <= T) {  // own pixels: publish value keys and seed labels
-                        const int64_t g = fbase + (int64_t)r * W + c;
+                        const int64_t g = fbase + rowoff(r, W) + c;
                         *reinterpret_cast<uint4 *>(val + g) = make_uint4(key[0], key[1], key[2], key[3]);
                         *reinterpret_cast<int4 *>(in.out + g) = make_int4(lab[0], lab[1], lab[2], lab[3]);
                     }
@@ -477,7 +477,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             for (int t = 0; t < TRIPS; ++t) {
                 const int idx = min(tid + NT * t, QUADS - 1);
                 const int lr = idx / QW, q = idx % QW;
-                const int64_t p = fbase + (int64_t)min(max(r0 + lr - 1, 0), H - 1) * W + min(max(c0 + 4 * q, 0), W - 4);
+                const int64_t p = fbase + rowoff(min(max(r0 + lr - 1, 0), H - 1), W) + min(max(c0 + 4 * q, 0), W - 4);
                 l4[t] = *reinterpret_cast<const uint4 *>(L + p);
                 v4[t] = *reinterpret_cast<const uint4 *>(val + p);
             }
@@ -507,13 +507,13 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             if (FIRST) {
                 lv = initial(r, c);
                 if (lr >= 1 && lr <= T && lc >= 1 && lc <= T) {  // own pixels: publish value key and seed label
-                    const int64_t g = fbase + (int64_t)r * W + c;
+                    const int64_t g = fbase + rowoff(r, W) + c;
                     val[g] = lv.y;
                     in.out[g] = lv.y != WS_INF ? in.markers[g] : 0;
                 }
             } else {
-                lv.x = L[fbase + (int64_t)r * W + c];
-                lv.y = val[fbase + (int64_t)r * W + c];
+                lv.x = L[fbase + rowoff(r, W) + c];
+                lv.y = val[fbase + rowoff(r, W) + c];
             }
         }
         sLV[lr * P + lc] = lv;
@@ -581,14 +581,14 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             const int r = r0 + lr, c = c0 + 4 * q;
             const uint2 *src = sLV + (lr + 1) * P + 1 + 4 * q;
             if (r >= 0 && r < H && c >= 0 && c < W)
-                *reinterpret_cast<uint4 *>(L + fbase + (int64_t)r * W + c) = make_uint4(src[0].x, src[1].x, src[2].x, src[3].x);
+                *reinterpret_cast<uint4 *>(L + fbase + rowoff(r, W) + c) = make_uint4(src[0].x, src[1].x, src[2].x, src[3].x);
         }
         return;
     }
     for (int i = tid; i < T * T; i += NT) {
         int lr = i / T, lc = i % T;
         int r = r0 + lr, c = c0 + lc;
-        if (r >= 0 && r < H && c >= 0 && c < W) L[fbase + (int64_t)r * W + c] = sLV[(lr + 1) * P + lc + 1].x;
+        if (r >= 0 && r < H && c >= 0 && c < W) L[fbase + rowoff(r, W) + c] = sLV[(lr + 1) * P + lc + 1].x;
     }
 }
 
@@ -760,7 +760,7 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
         for (int t = 0; t < TRIPS; ++t) {
             const int i = min((int)threadIdx.x + 256 * t, UF_SH * UF_SW - 1);
             const int r = r0 + i / UF_SW - 1, c = c0 + i % UF_SW - 1;
-            kv[t] = K[fbase + (int64_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)];
+            kv[t] = K[fbase + rowoff(min(max(r, 0), H - 1), W) + min(max(c, 0), W - 1)];
         }
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
@@ -778,7 +778,7 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
 #pragma unroll
     for (int k = 0; k < UF_LNS / 256; ++k) {
         const int t = threadIdx.x + k * 256;
-        fv[k] = F[fbase + (int64_t)min(r0 + t / UF_TW, H - 1) * W + min(c0 + t % UF_TW, W - 1)];
+        fv[k] = F[fbase + rowoff(min(r0 + t / UF_TW, H - 1), W) + min(c0 + t % UF_TW, W - 1)];
     }
 #pragma unroll
     for (int k = 0; k < UF_LNS / 256; ++k) {
@@ -798,10 +798,10 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
         self[k] = v;
         sM[t] = m8;
         if (r < H && c < W) {
-            minmask[fbase + (int64_t)r * W + c] = m8;
+            minmask[fbase + rowoff(r, W) + c] = m8;
             // the "component cannot be resolved" marks of this level start clear: every root the label passes will look at
             // lies in a tile this pass visits (instead of a memset of the whole array per level)
-            bad[fbase + (int64_t)r * W + c] = 0;
+            bad[fbase + rowoff(r, W) + c] = 0;
         }
     }
     __syncthreads();
@@ -855,7 +855,7 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
             const int lt = root & (UF_LNS - 1);
             v = ((r0 + lt / UF_TW) * W + c0 + lt % UF_TW) | (root >= UF_LNS ? UF_NS : 0);
         }
-        parent[fbase + (int64_t)r * W + c] = v;
+        parent[fbase + rowoff(r, W) + c] = v;
     }
 }
 
@@ -1001,44 +1001,92 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
 // fetched -- 1 byte of mask per pixel instead of 4 of labels.
 // (F carries no __restrict__: seed and root words are READ while the int4 stores of other lanes rewrite them with the
 // value they already hold -- seeds are the only labelled pixels before this pass and the pass never changes one)
+// Like ccl_relabel_quads_kernel a lane owns LABEL4_Q quads (LABEL4_Q * 1024 pixels per block, quad q of a lane 1024
+// pixels further on) and walks their chains -- parent entry, root, the root's label -- in lockstep: a lane with one
+// chain waits a memory latency per step (89 % of this kernel's wave cycles were waits).  A quad's chain belongs to its
+// first reachable pixel; a pixel with another parent entry walks on its own afterwards.
+constexpr int LABEL4_Q = 4;
+
 __global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ minmask,
                                                             int *F, uint8_t *__restrict__ bad, int *__restrict__ tie_flags,
                                                             int64_t n)
 {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t i0 = (int64_t)blockIdx.x * (1024 * LABEL4_Q) + threadIdx.x * 4;
     const int b = blockIdx.y;
-    if (i >= n) return;
     const int64_t fbase = (int64_t)b * n;
     const int *par = parent + fbase;
-    const int4 p4 = *reinterpret_cast<const int4 *>(par + i);
-    const unsigned m4 = *reinterpret_cast<const unsigned *>(minmask + fbase + i);
-    const int pv[4] = {p4.x, p4.y, p4.z, p4.w};
-    int fv[4] = {0, 0, 0, 0};  // unreachable pixels and pixels of components without a seed stay unlabelled
-    int last_p = -1, last_root = -1, last_lab = 0;
-    bool wrote = false;
+    int4 p4[LABEL4_Q];
+    unsigned m4[LABEL4_Q];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int x = pv[j];
-        if (x < 0) continue;
-        const bool seed = ((m4 >> (8 * j)) & 255u) == 0;
-        if (seed) fv[j] = F[fbase + i + j];
-        if (x != last_p) {
-            last_p = x;
-            int q;
-            while ((q = par[x & (UF_NS - 1)]) != x) x = q;
-            last_root = x;
-            last_lab = x < UF_NS ? F[fbase + x] : 0;  // roots are labelled pixels, never changed by this pass
-        }
-        if (last_root >= UF_NS) continue;  // no labelled pixel in the component
-        if (!seed) {
-            fv[j] = last_lab;
-            wrote = true;
-        } else if (fv[j] != last_lab) {
-            bad[fbase + last_root] = 1;
-            if (tie_flags[b] == 0) tie_flags[b] = 1;
+    for (int q = 0; q < LABEL4_Q; ++q) {
+        const int64_t i = i0 + q * 1024;
+        p4[q] = i < n ? *reinterpret_cast<const int4 *>(par + i) : make_int4(-1, -1, -1, -1);
+        m4[q] = i < n ? *reinterpret_cast<const unsigned *>(minmask + fbase + i) : 0u;
+    }
+    // (only the first lane of each run of lanes with the same entry walks; the others read its answer across lanes)
+    int lead[LABEL4_Q], root[LABEL4_Q], lab[LABEL4_Q], head_lane[LABEL4_Q];
+    const int lane = lane_id();
+#pragma unroll
+    for (int q = 0; q < LABEL4_Q; ++q) {
+        lead[q] = p4[q].x >= 0 ? p4[q].x : (p4[q].y >= 0 ? p4[q].y : (p4[q].z >= 0 ? p4[q].z : p4[q].w));
+        const int left = __shfl_up(lead[q], 1);
+        const bool head = lane == 0 || lead[q] != left;
+        const unsigned long long heads = __ballot(head);
+        head_lane[q] = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
+        root[q] = head ? lead[q] : -1;
+    }
+    bool more = true;
+    while (more) {
+        int nx[LABEL4_Q];
+#pragma unroll
+        for (int q = 0; q < LABEL4_Q; ++q) nx[q] = root[q] >= 0 ? par[root[q] & (UF_NS - 1)] : -1;
+        more = false;
+#pragma unroll
+        for (int q = 0; q < LABEL4_Q; ++q) {
+            more = more || nx[q] != root[q];
+            root[q] = nx[q];
         }
     }
-    if (wrote) *reinterpret_cast<int4 *>(F + fbase + i) = make_int4(fv[0], fv[1], fv[2], fv[3]);
+#pragma unroll
+    for (int q = 0; q < LABEL4_Q; ++q)
+        lab[q] = (root[q] >= 0 && root[q] < UF_NS) ? F[fbase + root[q]] : 0;  // roots are labelled pixels, never changed by this pass
+#pragma unroll
+    for (int q = 0; q < LABEL4_Q; ++q) {
+        root[q] = __shfl(root[q], head_lane[q]);
+        lab[q] = __shfl(lab[q], head_lane[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < LABEL4_Q; ++q) {
+        const int64_t i = i0 + q * 1024;
+        if (i >= n) continue;
+        const int pv[4] = {p4[q].x, p4[q].y, p4[q].z, p4[q].w};
+        int fv[4] = {0, 0, 0, 0};  // unreachable pixels and pixels of components without a seed stay unlabelled
+        int last_p = lead[q], last_root = root[q], last_lab = lab[q];
+        bool wrote = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int x = pv[j];
+            if (x < 0) continue;
+            const bool seed = ((m4[q] >> (8 * j)) & 255u) == 0;
+            if (seed) fv[j] = F[fbase + i + j];
+            if (x != last_p) {
+                last_p = x;
+                int t;
+                while ((t = par[x & (UF_NS - 1)]) != x) x = t;
+                last_root = x;
+                last_lab = x < UF_NS ? F[fbase + x] : 0;
+            }
+            if (last_root >= UF_NS) continue;  // no labelled pixel in the component
+            if (!seed) {
+                fv[j] = last_lab;
+                wrote = true;
+            } else if (fv[j] != last_lab) {
+                bad[fbase + last_root] = 1;
+                if (tie_flags[b] == 0) tie_flags[b] = 1;
+            }
+        }
+        if (wrote) *reinterpret_cast<int4 *>(F + fbase + i) = make_int4(fv[0], fv[1], fv[2], fv[3]);
+    }
 }
 
 // (3) proof check: every neighbour whose key equals the minimum neighbour key carries the pixel's label
@@ -1055,7 +1103,7 @@ __global__ void __launch_bounds__(256) ws_check_kernel(const KeyT *__restrict__ 
     if (frame_flags && frame_flags[b] == 0) return;
     const KeyT KINF = ~(KeyT)0;
     const int64_t fbase = (int64_t)b * H * W;
-    const int64_t i = fbase + (int64_t)r * W + c;
+    const int64_t i = fbase + rowoff(r, W) + c;
     const KeyT l = K[i];
     if ((unsigned)(l >> (8 * sizeof(KeyT) - 32)) == WS_INF) return;  // outside the mask or unreachable: stays 0
     if (mask[i] != 0 && markers[i] != 0) return;                     // seed: keeps its marker
@@ -1145,7 +1193,7 @@ __device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *_
         for (int t = 0; t < TRIPS; ++t) {
             const int i = min((int)threadIdx.x + 256 * t, WS_S * WS_S - 1);
             const int r = r0 + i / WS_S - 1, c = c0 + i % WS_S - 1;
-            const int64_t p = fbase + (int64_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1);
+            const int64_t p = fbase + rowoff(min(max(r, 0), H - 1), W) + min(max(c, 0), W - 1);
             lv[t] = L[p];
             kv[t] = K2[p];
             vv[t] = val[p];
@@ -1581,14 +1629,14 @@ __global__ void __launch_bounds__(64) ws_exact_kernel(const unsigned *__restrict
         const int rr = r0 + (t == 0 ? -1 : t == 3 ? 1 : 0), cc = c0 + (t == 1 ? -1 : t == 2 ? 1 : 0);
         bool open = false;
         unsigned qv = 0;
-        const int64_t q = (int64_t)rr * W + cc;
+        const int64_t q = rowoff(rr, W) + cc;
         if (t < 4 && rr >= 0 && rr < H && cc >= 0 && cc < W) {
             const uint8_t in_mask = ms[q];  // three independent loads, in flight together
             const int taken = o[q];
             qv = v[q];
             open = in_mask != 0 && taken == 0;
         }
-        const int lab = o[(int64_t)r0 * W + c0];
+        const int lab = o[rowoff(r0, W) + c0];
         ex_pop<D>(h);
         unsigned long long m = __ballot(open);
         while (m) {
@@ -1795,7 +1843,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             }
             if (first_level && act == nullptr && flist == nullptr && (W & 3) == 0 && (((uintptr_t)out | (uintptr_t)uf_parent) & 15) == 0 &&
                 ((uintptr_t)uf_mask & 3) == 0) {
-                PCSEG_LAUNCH(ws_uf_label4_kernel, dim3((unsigned)((npx / 4 + 255) / 256), B), dim3(256), 0, s,
+                PCSEG_LAUNCH(ws_uf_label4_kernel, dim3((unsigned)((npx + 1024 * LABEL4_Q - 1) / (1024 * LABEL4_Q)), B), dim3(256), 0, s,
                              (const int *)uf_parent, (const uint8_t *)uf_mask, out, uf_bad1, out_flags, npx);
                 PCSEG_CHECK_LAUNCH();
             } else if (first_level) {
