@@ -245,8 +245,7 @@ constexpr int COL_ROWS = PCSEG_COL_ROWS;
 #ifndef PCSEG_RED_WAVES
 #define PCSEG_RED_WAVES 2
 #endif
-// (the plane-free instantiation keeps no float64 accumulators: four blocks per CU instead of two -- it is a latency-bound
-// stream of 4 bytes per pixel; eight would cap it at 64 registers and spill: 502 us per launch against 190)
+// (NC == 0 is kept for completeness; the pipeline's plane-free pass is region_stats_col_kernel below)
 template <int NC>
 __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_reduce_col_kernel(const int *__restrict__ labels, const float *__restrict__ planes,
                                                                  const uint8_t *__restrict__ cls, unsigned long long sel, int C,
@@ -256,7 +255,8 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
     __shared__ int tags[RED_SLOTS];
     __shared__ int lstat[RED_SLOTS][8];
     __shared__ double lsum[NC > 0 ? RED_SLOTS : 1][RED_MAXC];
-    const int b = blockIdx.z;
+    const TileIndex ti = xcd_tile_index();  // (a frame's blocks on one XCD: their atomics on the frame's tables meet in one L2)
+    const int b = ti.z;
     const int64_t n = (int64_t)H * W;
     const int *lab = labels + (int64_t)b * n;
     const float *pl = NC > 0 ? planes + (int64_t)b * C * n : nullptr;
@@ -270,8 +270,8 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
     }
     __syncthreads();
     const RegionSlots ls{tags, lstat, lsum};
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int r0 = blockIdx.y * COL_ROWS, r1 = min(H, r0 + COL_ROWS);
+    const int c = (ti.x * 256 + threadIdx.x) * 4;
+    const int r0 = ti.y * COL_ROWS, r1 = min(H, r0 + COL_ROWS);
     if (c < W) {
         int cur[4] = {0, 0, 0, 0}, start[4] = {0, 0, 0, 0};
         int area[4] = {0, 0, 0, 0}, srow[4] = {0, 0, 0, 0};
@@ -396,8 +396,6 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
                 }
             }
                 };
-        // (an eight-row load look-ahead for the plane-free instantiation was measured: 225 us against 202 -- the walk is not
-        // waiting for its loads)
         fetch(r0);
         for (int r = r0; r <= r1; ++r) {
             const int4 l4 = l4n;
@@ -421,6 +419,152 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
         region_slots_flush(lstat[i], gst + (int64_t)(l - 1) * 8);
         if (NC > 0)
             for (int k = 0; k < C; ++k) atomicAdd(&gsum[(int64_t)(l - 1) * C + k], lsum[i][k]);
+    }
+}
+
+// ---- the plane-free pass (area, centroid sums, bounding box, first pixel): 4 bytes per pixel.
+// Same column walk, but a vertical run is just (label, first row, end row) -- its area, row sum and column sum follow --
+// and what bounds the pass is not the walk (64 us with the commits taken out: 4.2 TB/s) but the LDS atomics of the
+// commits, eight per run and column, most of them aimed at the slot the neighbouring lanes aim at too (72 us), and the
+// block's flush to the frame's table (55 us).  So a finished run is PARKED in two registers, and at the end of the block
+// the wave adds up the runs of ADJACENT LANES THAT CARRY THE SAME LABEL with a segmented shuffle reduction -- a region a
+// few dozen pixels wide is eight lanes -- and only the first lane of each segment goes to the LDS table.
+// (measured on the way: a four- and an eight-row load ring on the old form, 180 and 197 us against 179 -- not the loads;
+// parking alone, every lane still committing for itself at the end: 200 us against 185 -- the atomics, not the branch.)
+#ifndef PCSEG_STATS_ROWS
+#define PCSEG_STATS_ROWS 32
+#endif
+constexpr int STATS_ROWS = PCSEG_STATS_ROWS;  // rows per block of the plane-free pass (block partials must fit 32 bits: <= 64)
+static_assert(STATS_ROWS <= 64, "block-local sums are 32-bit");
+
+struct RunSum {
+    int label;  // 0 = none
+    int area, srow, scol, rmin, rmax1, cmin, cmax, first;
+};
+
+__device__ __forceinline__ RunSum run_sum(int label, int start, int end, int col, int W)
+{
+    const int area = end - start;
+    return RunSum{label, area, __mul24(area, start) + ((area * (area - 1)) >> 1), __mul24(col, area), start, end, col, col,
+                  __mul24(start, W) + col};
+}
+
+__device__ __forceinline__ void run_merge(RunSum &a, const RunSum &o)
+{
+    a.area += o.area; a.srow += o.srow; a.scol += o.scol;
+    a.rmin = min(a.rmin, o.rmin); a.rmax1 = max(a.rmax1, o.rmax1);
+    a.cmin = min(a.cmin, o.cmin); a.cmax = max(a.cmax, o.cmax); a.first = min(a.first, o.first);
+}
+
+__device__ __forceinline__ void run_commit(const RegionSlots &ls, long long *gst, int *overflow, int b, int cap, const RunSum &a)
+{
+    region_commit<0>(ls, gst, nullptr, overflow, b, cap, 0, a.label, a.area, a.srow, a.scol, a.rmin, a.rmax1, a.cmin, a.cmax, a.first,
+                     nullptr);
+}
+
+// all 64 lanes call this (label 0 = nothing to add): lanes next to each other with the same label are summed into the
+// first of them, which commits
+__device__ __forceinline__ void wave_commit(const RegionSlots &ls, long long *gst, int *overflow, int b, int cap, RunSum a)
+{
+    const int lane = lane_id();
+    const int left = __shfl_up(a.label, 1);
+    const bool head = lane == 0 || a.label != left;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long after = lane == 63 ? 0ull : heads >> (lane + 1);
+    const int remain = after ? __ffsll((long long)after) - 1 : 63 - lane;  // lanes after this one in its segment
+    for (int off = 1; off < 64; off <<= 1) {
+        RunSum o;
+        o.area = __shfl_down(a.area, off); o.srow = __shfl_down(a.srow, off); o.scol = __shfl_down(a.scol, off);
+        o.rmin = __shfl_down(a.rmin, off); o.rmax1 = __shfl_down(a.rmax1, off); o.cmin = __shfl_down(a.cmin, off);
+        o.cmax = __shfl_down(a.cmax, off); o.first = __shfl_down(a.first, off);
+        if (off <= remain) run_merge(a, o);
+    }
+    if (head && a.label > 0) run_commit(ls, gst, overflow, b, cap, a);
+}
+
+__global__ void __launch_bounds__(256, 4) region_stats_col_kernel(const int *__restrict__ labels, int H, int W, int cap,
+                                                                   long long *__restrict__ stats, int *__restrict__ overflow)
+{
+    __shared__ int tags[RED_SLOTS];
+    __shared__ int lstat[RED_SLOTS][8];
+    // every block of a frame adds to the same few lines of the frame's table (the background's, the particle's): with a
+    // frame's blocks on ONE XCD those atomics meet in one L2 instead of bouncing the line between eight
+    const TileIndex ti = xcd_tile_index();
+    const int b = ti.z;
+    const int64_t n = (int64_t)H * W;
+    const int *lab = labels + (int64_t)b * n;
+    long long *gst = stats + (int64_t)b * cap * 8;
+    for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
+        tags[i] = 0;
+        region_slots_clear(lstat[i], H, W);
+    }
+    __syncthreads();
+    const RegionSlots ls{tags, lstat, nullptr};
+    const int c = (ti.x * 256 + threadIdx.x) * 4;
+    const int r0 = ti.y * STATS_ROWS, r1 = min(H, r0 + STATS_ROWS);
+    // (lanes beyond the frame's width walk zeros: the reductions at the end want all 64 lanes)
+    const bool inside = c < W;
+    int cur[4] = {0, 0, 0, 0}, start[4] = {0, 0, 0, 0};
+    int parked_label[4] = {0, 0, 0, 0}, parked_rows[4] = {0, 0, 0, 0};  // first row | end row << 16 (rows < 2^15)
+    const int *at = lab + rowoff(r0, W) + (inside ? c : 0);
+    int4 l4n = inside ? *reinterpret_cast<const int4 *>(at) : make_int4(0, 0, 0, 0);
+    for (int r = r0; r < r1; ++r) {
+        const int4 l4 = l4n;
+        landed(l4);
+        at += W;
+        if (inside && r + 1 < r1) l4n = *reinterpret_cast<const int4 *>(at);
+        const int ll[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ll[j] != cur[j]) {
+                if (cur[j] > 0) {
+                    // (a column seldom ends two runs inside one block)
+                    if (parked_label[j])
+                        run_commit(ls, gst, overflow, b, cap,
+                                   run_sum(parked_label[j], parked_rows[j] & 0xFFFF, parked_rows[j] >> 16, c + j, W));
+                    parked_label[j] = cur[j];
+                    parked_rows[j] = start[j] | (r << 16);
+                }
+                cur[j] = ll[j];
+                start[j] = r;
+            }
+        }
+    }
+    // end of the block: the open runs and the parked ones, each folded over the lane's four columns first (they usually sit
+    // in the same region), then over the lanes
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        RunSum q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            q[j] = pass == 0 ? run_sum(cur[j], start[j], r1, c + j, W)
+                             : run_sum(parked_label[j], parked_rows[j] & 0xFFFF, parked_rows[j] >> 16, c + j, W);
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < j; ++i)
+                if (q[j].label > 0 && q[j].label == q[i].label) {
+                    run_merge(q[i], q[j]);
+                    q[j].label = 0;
+                }
+        // a lane whose first column carries no label hands another column's run to the lane reduction instead
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (q[0].label <= 0 && q[j].label > 0) {
+                q[0] = q[j];
+                q[j].label = 0;
+            }
+        if (q[0].label < 0) q[0].label = 0;
+        wave_commit(ls, gst, overflow, b, cap, q[0]);
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (q[j].label > 0) run_commit(ls, gst, overflow, b, cap, q[j]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
+        const int l = tags[i];
+        if (l == 0) continue;
+        region_slots_flush(lstat[i], gst + (int64_t)(l - 1) * 8);
     }
 }
 
@@ -472,7 +616,8 @@ __global__ void __launch_bounds__(256, (NC <= 5 && !STATS_B) ? 3 : 2) region_sum
     __shared__ int tags_a[RED_SLOTS], tags_b[RED_SLOTS];
     __shared__ double lsum_a[RED_SLOTS][RED_MAXC], lsum_b[RED_SLOTS][RED_MAXC];
     __shared__ int lstat_b[STATS_B ? RED_SLOTS : 1][8];
-    const int b = blockIdx.z;
+    const TileIndex ti = xcd_tile_index();  // (a frame's blocks on one XCD: their atomics on the frame's tables meet in one L2)
+    const int b = ti.z;
     const int64_t n = (int64_t)H * W;
     const int *la = labels_a + (int64_t)b * n, *lb = labels_b + (int64_t)b * n;
     const float *pl = planes + (int64_t)b * C * n;
@@ -487,8 +632,8 @@ __global__ void __launch_bounds__(256, (NC <= 5 && !STATS_B) ? 3 : 2) region_sum
     __syncthreads();
     const SumSlots sa{tags_a, lsum_a}, sb{tags_b, lsum_b};
     const RegionSlots sbb{tags_b, lstat_b, lsum_b};
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int r0 = blockIdx.y * COL_ROWS, r1 = min(H, r0 + COL_ROWS);
+    const int c = (ti.x * 256 + threadIdx.x) * 4;
+    const int r0 = ti.y * COL_ROWS, r1 = min(H, r0 + COL_ROWS);
     if (c < W) {
         int cur_a[4] = {0, 0, 0, 0}, cur_b[4] = {0, 0, 0, 0};
         int start_b[4] = {0, 0, 0, 0}, area_b[4] = {0, 0, 0, 0};
@@ -1095,8 +1240,8 @@ int pcseg_region_reduce_sel(const int32_t *labels, const int32_t *counts, const 
         PCSEG_LAUNCH(region_reduce_col_kernel<8>, cgrid, dim3(256), 0, s, labels, planes, cls, sel, C, H, W, cap, (long long *)stats, sums,
                      overflow);
     else if (vec)
-        PCSEG_LAUNCH(region_reduce_col_kernel<0>, cgrid, dim3(256), 0, s, labels, planes, cls, sel, C, H, W, cap, (long long *)stats, sums,
-                     overflow);
+        PCSEG_LAUNCH(region_stats_col_kernel, dim3(cgrid.x, (H + STATS_ROWS - 1) / STATS_ROWS, B), dim3(256), 0, s, labels, H, W, cap,
+                     (long long *)stats, overflow);
     else if (planes)
         PCSEG_LAUNCH(region_reduce_kernel<true>, grid, dim3(256), 0, s, labels, planes, cls, sel, C, H, W, cap, (long long *)stats,
                            sums, overflow);
