@@ -149,10 +149,15 @@ __device__ __forceinline__ unsigned ld_agent(const unsigned *p)
 }
 
 // ---- LDS union-find
-__device__ __forceinline__ int find_lds(volatile int *par, int x)
+// (relaxed workgroup-scope atomic accesses, not `volatile`: the compiler keeps a volatile access through a pointer
+// argument in the generic address space -- flat_load / flat_store instead of ds_read / ds_write, 68 of them in the
+// watershed tile pass -- while it does infer LDS for these)
+__device__ __forceinline__ int ld_lds(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_lds(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int find_lds(int *par, int x)
 {
     int p;
-    while ((p = par[x]) != x) x = p;
+    while ((p = ld_lds(par + x)) != x) x = p;
     return x;
 }
 __device__ __forceinline__ void unite_lds(int *par, int a, int b)

@@ -692,13 +692,13 @@ constexpr int UF_TW = 64, UF_TH = 32, UF_SW = UF_TW + 2, UF_SH = UF_TH + 2;
 constexpr int UF_LNS = UF_TW * UF_TH;  // non-seed offset of tile-local virtual indices
 constexpr int UF_NS = 1 << 30;         // non-seed offset of frame-wide virtual indices (H * W < 2^30)
 
-__device__ __forceinline__ int vfind_lds(volatile int *par, int v)
+__device__ __forceinline__ int vfind_lds(int *par, int v)
 {
     // path halving: re-pointing v at its grandparent keeps it inside its set (concurrent unions only ever lower parents)
     int p;
-    while ((p = par[v & (UF_LNS - 1)]) != v) {
-        const int g = par[p & (UF_LNS - 1)];
-        if (g != p) par[v & (UF_LNS - 1)] = g;
+    while ((p = ld_lds(par + (v & (UF_LNS - 1)))) != v) {
+        const int g = ld_lds(par + (p & (UF_LNS - 1)));
+        if (g != p) st_lds(par + (v & (UF_LNS - 1)), g);
         v = g;
     }
     return v;
@@ -1404,9 +1404,15 @@ __global__ void ws_set_flags_kernel(int *flags, int B, int v)
 constexpr int EX_LDS_BIG = 8192, EX_LDS_SMALL = PCSEG_EX_SMALL_LDS, EX_D_BIG = 6, EX_D_SMALL = PCSEG_EX_SMALL_D;
 static_assert((EX_LDS_SMALL & (EX_LDS_SMALL - 1)) == 0 && EX_LDS_SMALL >= (2 << EX_D_SMALL), "the first window must fit the LDS share");
 
+// (the LDS halves are typed by address space: with four generic pointers the compiler folds `d < lds ? lk[d] : gk[d]` into
+// ONE flat access through a selected pointer -- 18 flat loads / stores per pop and push, each of which waits on both the
+// LDS and the memory counter)
+typedef __attribute__((address_space(3))) unsigned long long ex_lds_key_t;
+typedef __attribute__((address_space(3))) unsigned ex_lds_idx_t;
+
 struct ExactHeap {
-    unsigned long long *lk;  // LDS keys   (slot d at lk[d], slot 0 unused)
-    unsigned *lx;            // LDS pixel indices
+    ex_lds_key_t *lk;  // LDS keys   (slot d at lk[d], slot 0 unused)
+    ex_lds_idx_t *lx;  // LDS pixel indices
     unsigned long long *gk;  // workspace keys (slot d at gk[d])
     unsigned *gx;
     int lds;  // slots below this index live in LDS
@@ -1493,8 +1499,8 @@ __device__ __forceinline__ void ex_children(const ExactHeap &h, long long d, uns
         key2_t k;
         idx2_t x;
         if (FROM_LDS) {
-            k = *(const key2_t *)(h.lk + 2 * d);
-            x = *(const idx2_t *)(h.lx + 2 * d);
+            k = *(const __attribute__((address_space(3))) key2_t *)(h.lk + 2 * d);
+            x = *(const __attribute__((address_space(3))) idx2_t *)(h.lx + 2 * d);
         } else {
             k = *(const key2_glb_t *)(h.gk + 2 * d);
             x = *(const idx2_glb_t *)(h.gx + 2 * d);
@@ -1608,7 +1614,7 @@ __global__ void __launch_bounds__(64) ws_exact_kernel(const unsigned *__restrict
     const int t = threadIdx.x;
     // slot d (1-based) of the heap is element d - 1 of the sequential heap.  Slots >= EX_LDS live in the workspace, which
     // holds n elements per frame: slot d -> element d - 1, so that slot n (every pixel is pushed at most once) still fits
-    ExactHeap h{lds_key, lds_idx, heap_key + (int64_t)b * n - 1, heap_idx + (int64_t)b * n - 1, EX_LDS, 0, 0ull, 0u};
+    ExactHeap h{(ex_lds_key_t *)lds_key, (ex_lds_idx_t *)lds_idx, heap_key + (int64_t)b * n - 1, heap_idx + (int64_t)b * n - 1, EX_LDS, 0, 0ull, 0u};
     for (int64_t base = 0; base < n; base += WAVE) {
         const int64_t i = base + t;
         const int seed = i < n ? o[i] : 0;
