@@ -80,6 +80,42 @@ def _agree_planes(local_planes, group, device):
     return int(t.item())
 
 
+class _HostRows:
+    """A rank's table rows in pinned host memory, filled batch by batch on a copy stream of its own while newer batches
+    compute (one rank: there is nothing to gather, and downloading the whole dataset's tables after the last batch -- 0.5 GB
+    for 1 024 frames -- cost as much as two batches' kernels).  The buffers are sized from the first batch and the number
+    of batches to come; a table that outgrows its buffer moves to one twice the size."""
+
+    def __init__(self, device, expected_batches):
+        self.device = device
+        self.expected = max(1, int(expected_batches))
+        self.stream = torch.cuda.Stream(device=device)
+        self.buf, self.rows = {}, {}
+
+    def append(self, part):
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        for k, t in part.items():
+            n, cols = int(t.shape[0]), int(t.shape[1])
+            if k not in self.buf:
+                self.buf[k] = torch.empty((int(n * self.expected * 1.15) + 4096, cols), dtype=t.dtype, pin_memory=True)
+                self.rows[k] = 0
+            used = self.rows[k]
+            if used + n > self.buf[k].shape[0]:
+                self.stream.synchronize()  # the copies into the old buffer
+                grown = torch.empty((2 * (used + n), cols), dtype=t.dtype, pin_memory=True)
+                grown[:used] = self.buf[k][:used]
+                self.buf[k] = grown
+            if n:
+                with torch.cuda.stream(self.stream):
+                    self.buf[k][used:used + n].copy_(t, non_blocking=True)
+                t.record_stream(self.stream)
+            self.rows[k] = used + n
+
+    def finish(self):
+        self.stream.synchronize()
+        return {k: self.buf[k][:self.rows[k]].numpy() for k in self.buf}
+
+
 def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, planes=None, check=True, **table_kwargs):
     """BASELINE configs 3 / 5: frames ``rank, rank + world, ...`` of a dataset go through ``pipe`` in batches of
     ``batch`` and the tables of all ranks are gathered once at the end.  ``make_batch(frame_ids)`` returns the
@@ -99,6 +135,18 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
     mine = shard_frames(n_frames, rank, world)
     ratio_kw = {k: table_kwargs[k] for k in ("ratios", "distances", "raster") if k in table_kwargs}
     parts = []
+    n_batches = (len(mine) + batch - 1) // batch
+    host_rows = None  # one rank: the rows go to the host as the batches finish (see _HostRows)
+
+    def take(part):
+        nonlocal host_rows
+        if world == 1 and all(isinstance(v, torch.Tensor) and v.is_cuda and v.ndim == 2 for v in part.values()):
+            if host_rows is None:
+                host_rows = _HostRows(next(iter(part.values())).device, n_batches)
+            host_rows.append(part)
+        else:
+            parts.append(part)
+
     pending = collections.deque()
     depth = max(1, int(getattr(pipe, "lanes", 1)))  # batches the pipeline keeps in flight: a table is assembled (which
     seen_planes = 0
@@ -112,16 +160,19 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
         # under the other lanes' kernels
         while getattr(pipe, "graph", False) and len(pending) >= depth:
             res, rid = pending.popleft()
-            parts.append(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
+            take(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
         pending.append((pipe.run(frames), ids))
         if len(pending) > depth:
             res, rid = pending.popleft()
-            parts.append(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
+            take(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
     while pending:
         res, rid = pending.popleft()
-        parts.append(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
+        take(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
     if planes is None:
         planes = _agree_planes(seen_planes, group, device) or 5
+    if host_rows is not None:
+        # (one rank's rows come out of the batches in frame order, labels ascending: that IS the gathered order)
+        return pipe.host_tables(host_rows.finish(), planes, **table_kwargs)
     if parts:
         merged = {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
     else:
