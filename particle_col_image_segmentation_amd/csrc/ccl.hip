@@ -130,13 +130,19 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(KeyFn keyfn, int *__res
     const int64_t fbase = (int64_t)b * H * W;
     int *par = parent + fbase;
     const int p = r * W + c;
+    // the five keys as ONE batch of loads (clamped coordinates: every address is valid, what lies outside the frame is
+    // masked afterwards) -- tested one after the other they were five dependent memory round trips per pixel
+    // (candidate bits are sparse and their key costs two loads: there the pixel's own key is tested first)
+    const int rn = max(r - 1, 0), cw = max(c - 1, 0), ce = min(c + 1, W - 1);
     const int k = keyfn(b, r, c);
+    if (std::is_same<KeyFn, KeyCandBits>::value && k == 0) return;
+    const int k_w = keyfn(b, r, cw), k_n = keyfn(b, rn, c), k_nw = keyfn(b, rn, cw), k_ne = CONN8 ? keyfn(b, rn, ce) : 0;
     if (k == 0) return;
     // the same "implied link" rule as inside a tile: a link is skipped when the two pixels are already joined through
     // a third one whose links are made elsewhere (run links inside a tile row, vertical links of the left neighbour)
-    const bool w_same = c > 0 && keyfn(b, r, c - 1) == k;
-    const bool n_same = r > 0 && keyfn(b, r - 1, c) == k;
-    const bool nw_same = r > 0 && c > 0 && keyfn(b, r - 1, c - 1) == k;
+    const bool w_same = c > 0 && k_w == k;
+    const bool n_same = r > 0 && k_n == k;
+    const bool nw_same = r > 0 && c > 0 && k_nw == k;
     // (at a tile corner both the W and the N link cross tiles and would justify each other: keep both there)
     const bool corner = top && left;
     if (left && w_same && (corner || !(n_same && nw_same))) unite_glb(par, p, p - 1);
@@ -144,7 +150,7 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(KeyFn keyfn, int *__res
         if (top && n_same && (corner || !(w_same && nw_same))) unite_glb(par, p, p - W);
         if (CONN8) {
             if ((top || left) && nw_same && !n_same && !w_same) unite_glb(par, p, p - W - 1);
-            if (c + 1 < W && (top || right) && !n_same && keyfn(b, r - 1, c + 1) == k) unite_glb(par, p, p - W + 1);
+            if (c + 1 < W && (top || right) && !n_same && k_ne == k) unite_glb(par, p, p - W + 1);
         }
     }
 }
@@ -723,27 +729,25 @@ __global__ void __launch_bounds__(256) bitrun_border_kernel(const unsigned *__re
     const bool edge_col = col == 0 || col == BR_TW - 1;
     if (!tile_left && !tile_top && !(edge_col && ch > 0)) return;
     const unsigned *wb = bits + (int64_t)b * nch * W;
-    const unsigned w = wb[rowoff(ch, W) + c];
+    // the five words as one batch of loads (clamped at the frame's edge, where the value is not used) instead of up to
+    // four dependent round trips
+    const int cl = c > 0 ? c - 1 : c, cr = c + 1 < W ? c + 1 : c, chu = ch > 0 ? ch - 1 : ch;
+    const unsigned w = wb[rowoff(ch, W) + c], wl = wb[rowoff(ch, W) + cl];
+    const unsigned wu = wb[rowoff(chu, W) + c], wul = wb[rowoff(chu, W) + cl], wur = wb[rowoff(chu, W) + cr];
     if (w == 0) return;
     int *par = parent + (int64_t)b * H * W;
     const int row0 = ch * 32;
     if (tile_left)
-        bitrun_left_links(w, wb[rowoff(ch, W) + c - 1], [&](int a, int st) { unite_glb(par, (row0 + a) * W + c, (row0 + st) * W + c - 1); });
+        bitrun_left_links(w, wl, [&](int a, int st) { unite_glb(par, (row0 + a) * W + c, (row0 + st) * W + c - 1); });
     if ((w & 1u) && ch > 0) {
         const int node = row0 * W + c;
-        const unsigned wu = wb[rowoff((ch - 1), W) + c];
         if (wu >> 31) {
             if (tile_top) unite_glb(par, node, (row0 - 32 + bitrun_start(wu, 31)) * W + c);
         } else {
             // diagonals: made in LDS unless the word above is in another tile row, or the neighbour column in another tile
-            if (c > 0 && (tile_top || col == 0)) {
-                const unsigned wd = wb[rowoff((ch - 1), W) + c - 1];
-                if (wd >> 31) unite_glb(par, node, (row0 - 32 + bitrun_start(wd, 31)) * W + c - 1);
-            }
-            if (c + 1 < W && (tile_top || col == BR_TW - 1)) {
-                const unsigned wd = wb[rowoff((ch - 1), W) + c + 1];
-                if (wd >> 31) unite_glb(par, node, (row0 - 32 + bitrun_start(wd, 31)) * W + c + 1);
-            }
+            if (c > 0 && (tile_top || col == 0) && (wul >> 31)) unite_glb(par, node, (row0 - 32 + bitrun_start(wul, 31)) * W + c - 1);
+            if (c + 1 < W && (tile_top || col == BR_TW - 1) && (wur >> 31))
+                unite_glb(par, node, (row0 - 32 + bitrun_start(wur, 31)) * W + c + 1);
         }
     }
 }

@@ -185,11 +185,29 @@ __device__ __forceinline__ int find_glb(int *par, int x)
     }
     return x;
 }
+// the two walks to the roots advance in LOCKSTEP (path halving on both, as in find_glb): a step of the pair is two
+// independent loads in flight instead of one, and the border passes are nothing but these dependent walks
+__device__ __forceinline__ void find2_glb(int *par, int &a, int &b)
+{
+    for (;;) {
+        if (a == b) return;
+        const int pa = ld_agent(par + a), pb = ld_agent(par + b);
+        if (pa == a && pb == b) return;
+        const int ga = ld_agent(par + pa), gb = ld_agent(par + pb);
+        if (pa != a) {
+            if (ga != pa) __hip_atomic_store(par + a, ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a = ga;
+        }
+        if (pb != b) {
+            if (gb != pb) __hip_atomic_store(par + b, gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b = gb;
+        }
+    }
+}
 __device__ __forceinline__ void unite_glb(int *par, int a, int b)
 {
     for (;;) {
-        a = find_glb(par, a);
-        b = find_glb(par, b);
+        find2_glb(par, a, b);
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }
         int old = atomicMin(par + a, b);

@@ -730,8 +730,21 @@ __device__ __forceinline__ void vunite_glb(int *par, int p, int q)
 {
     int a = ld_agent(par + p), b = ld_agent(par + q);
     for (;;) {
-        a = vfind_glb(par, a);
-        b = vfind_glb(par, b);
+        // both walks in lockstep (see find2_glb)
+        for (;;) {
+            if (a == b) return;
+            const int pa = ld_agent(par + (a & (UF_NS - 1))), pb = ld_agent(par + (b & (UF_NS - 1)));
+            if (pa == a && pb == b) break;
+            const int ga = ld_agent(par + (pa & (UF_NS - 1))), gb = ld_agent(par + (pb & (UF_NS - 1)));
+            if (pa != a) {
+                if (ga != pa) __hip_atomic_store(par + (a & (UF_NS - 1)), ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a = ga;
+            }
+            if (pb != b) {
+                if (gb != pb) __hip_atomic_store(par + (b & (UF_NS - 1)), gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b = gb;
+            }
+        }
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }
         int old = atomicMin(par + (a & (UF_NS - 1)), b);
@@ -911,29 +924,24 @@ __global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict
     int *par = parent + fbase;
     const int p = r * W + c;
     const uint8_t *mm = minmask + fbase;
-    const uint8_t mp = mm[p];
+    // the four masks as one batch of loads (offsets clamped at the frame's edge, where the value is not used): tested one
+    // after the other they were up to four dependent memory round trips per pixel
+    const int up = r > 0 ? W : 0, lf = c > 0 ? 1 : 0;
+    const uint8_t mp = mm[p], mu = mm[p - up], ml = mm[p - lf], mul = mm[p - up - lf];
     // A cross-tile link is skipped when three links that are made anyway already join the two pixels: for a vertical
     // one the horizontal links p ~ p-1 and p-W ~ p-W-1 (both inside one tile) and the vertical link of p-1; likewise
     // for a horizontal one.  (At a tile corner both links cross tiles and would justify each other: keep both there.)
     if (top && ws_active(active, b, r - 1, c, tilesX, tilesY)) {
-        const uint8_t mu = mm[p - W];
         if ((mp & 1) || (mu & 8)) {
             bool implied = false;
-            if (!left && c > 0) {
-                const uint8_t ml = mm[p - 1], mul = mm[p - W - 1];
-                implied = ((mp & 2) || (ml & 4)) && ((mu & 2) || (mul & 4)) && ((ml & 1) || (mul & 8));
-            }
+            if (!left && c > 0) implied = ((mp & 2) || (ml & 4)) && ((mu & 2) || (mul & 4)) && ((ml & 1) || (mul & 8));
             if (!implied) vunite_glb(par, p, p - W);
         }
     }
     if (left && ws_active(active, b, r, c - 1, tilesX, tilesY)) {
-        const uint8_t ml = mm[p - 1];
         if ((mp & 2) || (ml & 4)) {
             bool implied = false;
-            if (!top && r > 0) {
-                const uint8_t mu = mm[p - W], mul = mm[p - W - 1];
-                implied = ((mp & 1) || (mu & 8)) && ((ml & 1) || (mul & 8)) && ((mu & 2) || (mul & 4));
-            }
+            if (!top && r > 0) implied = ((mp & 1) || (mu & 8)) && ((ml & 1) || (mul & 8)) && ((mu & 2) || (mul & 4));
             if (!implied) vunite_glb(par, p, p - 1);
         }
     }
