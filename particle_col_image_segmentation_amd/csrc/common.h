@@ -172,6 +172,25 @@ __device__ __forceinline__ void unite_lds(int *par, int a, int b)
         a = old;
     }
 }
+// the same with both walks in lockstep (two independent LDS reads per step).  Pays in the class-map tile pass (451 -> 434
+// us); the run-based tile pass got slower with it (155 -> 168 us) and so did the watershed's, which is bound by its
+// vector instructions, not by LDS latency (360 -> 424 us): they keep the plain form.
+__device__ __forceinline__ void unite_lds_pair(int *par, int a, int b)
+{
+    for (;;) {
+        for (;;) {
+            if (a == b) return;
+            const int pa = ld_lds(par + a), pb = ld_lds(par + b);
+            if (pa == a && pb == b) break;
+            a = pa;
+            b = pb;
+        }
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(&par[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
 
 // ---- global union-find (parents only ever decrease; stale reads cost iterations, never correctness)
 __device__ __forceinline__ int find_glb(int *par, int x)

@@ -68,11 +68,11 @@ __device__ __forceinline__ void ccl_tile_unions(const int *key, int *par)
         bool w = lc > 0 && key[i - 1] == k;
         bool n = key[i - CCL_TW] == k;
         bool nw = lc > 0 && key[i - CCL_TW - 1] == k;
-        if (n && !(w && nw)) unite_lds(par, i, i - CCL_TW);
+        if (n && !(w && nw)) unite_lds_pair(par, i, i - CCL_TW);
         if (CONN8) {
             bool ne = lc < CCL_TW - 1 && key[i - CCL_TW + 1] == k;
-            if (ne && !n) unite_lds(par, i, i - CCL_TW + 1);
-            if (nw && !n && !w) unite_lds(par, i, i - CCL_TW - 1);
+            if (ne && !n) unite_lds_pair(par, i, i - CCL_TW + 1);
+            if (nw && !n && !w) unite_lds_pair(par, i, i - CCL_TW - 1);
         }
     }
     __syncthreads();
