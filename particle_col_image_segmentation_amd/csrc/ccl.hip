@@ -574,20 +574,32 @@ __global__ void __launch_bounds__(256) set_bits4_multi_kernel(const uint8_t *__r
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[m][j] = 0;
-#pragma unroll 4
-    for (int j = 0; j < 32; ++j) {
-        const int r = ch * 32 + j;
-        if (r < H) {
-            const unsigned v = *reinterpret_cast<const unsigned *>(src + rowoff(r, W));
+    // eight rows' loads in flight at a time (a row test around each load made them 32 dependent round trips): rows past
+    // the frame's end re-read its last row and are masked out of the words
+#pragma unroll 1
+    for (int j0 = 0; j0 < 32; j0 += 8) {
+        unsigned v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = *reinterpret_cast<const unsigned *>(src + rowoff(min(ch * 32 + j0 + j, H - 1), W));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const unsigned a = (v >> (8 * q)) & 255u;
+                const unsigned a = (v8[j] >> (8 * q)) & 255u;
                 const unsigned long long sel = a < 64 ? (1ull << a) : 0ull;
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
-                    if (m < masks.n && (masks.bits[m] & sel)) w[m][q] |= 1u << j;
+                    if (m < masks.n && (masks.bits[m] & sel)) w[m][q] |= 1u << (j0 + j);
             }
         }
+    }
+    {
+        const int rows = min(32, H - ch * 32);
+        const unsigned valid = rows >= 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[m][q] &= valid;
     }
     const int64_t plane = (int64_t)B * nch * W;
 #pragma unroll

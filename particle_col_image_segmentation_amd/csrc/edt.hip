@@ -94,17 +94,21 @@ __global__ void __launch_bounds__(256) edt_bits4_kernel(Fg fg, unsigned *__restr
     const uint8_t *src = fg.p + (int64_t)b * H * W + c;
     const int r0 = ch * EDT_CH;
     unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-#pragma unroll 8
+    // all 32 rows' loads in flight together (a row test around each load made them 32 dependent round trips): rows past the
+    // frame's end re-read its last row and are masked out of the words
+    unsigned v[EDT_CH];
+#pragma unroll
+    for (int j = 0; j < EDT_CH; ++j) v[j] = *reinterpret_cast<const unsigned *>(src + rowoff(min(r0 + j, H - 1), W));
+#pragma unroll
     for (int j = 0; j < EDT_CH; ++j) {
-        const int r = r0 + j;
-        if (r < H) {
-            const unsigned v = *reinterpret_cast<const unsigned *>(src + rowoff(r, W));
-            if (fg.byte(v & 255u)) w0 |= 1u << j;
-            if (fg.byte((v >> 8) & 255u)) w1 |= 1u << j;
-            if (fg.byte((v >> 16) & 255u)) w2 |= 1u << j;
-            if (fg.byte(v >> 24)) w3 |= 1u << j;
-        }
+        if (fg.byte(v[j] & 255u)) w0 |= 1u << j;
+        if (fg.byte((v[j] >> 8) & 255u)) w1 |= 1u << j;
+        if (fg.byte((v[j] >> 16) & 255u)) w2 |= 1u << j;
+        if (fg.byte(v[j] >> 24)) w3 |= 1u << j;
     }
+    const int rows = min(EDT_CH, H - r0);
+    const unsigned valid = rows >= 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
+    w0 &= valid; w1 &= valid; w2 &= valid; w3 &= valid;
     *reinterpret_cast<uint4 *>(bits + ((int64_t)b * nch + ch) * W + c) = make_uint4(w0, w1, w2, w3);
 }
 
