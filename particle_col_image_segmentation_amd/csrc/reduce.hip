@@ -1050,7 +1050,10 @@ __device__ __forceinline__ double npy_floor_divide(double a, double b)
     return fl;
 }
 
-__global__ void __launch_bounds__(256) classify_regions_kernel(const long long *__restrict__ stats, const uint8_t *__restrict__ cls_out,
+// one block of CLS_THREADS per frame: the passes over the frame's few thousand regions are loops of dependent loads, so
+// the block is as wide as a block gets (256 threads: 63 us a launch, 1024: 21)
+constexpr int CLS_THREADS = 1024;
+__global__ void __launch_bounds__(CLS_THREADS) classify_regions_kernel(const long long *__restrict__ stats, const uint8_t *__restrict__ cls_out,
                                                                 const int *__restrict__ counts, ClassTables tab,
                                                                 uint8_t *__restrict__ kind, uint8_t *__restrict__ slot_of,
                                                                 int *__restrict__ cells, long long *__restrict__ particle_area,
@@ -1062,7 +1065,6 @@ __global__ void __launch_bounds__(256) classify_regions_kernel(const long long *
     __shared__ unsigned long long s_particle;
     __shared__ int s_first[CLS_T], s_ncell[CLS_T], s_nclu[CLS_T], s_base[CLS_T];
     __shared__ unsigned long long s_sumcell[CLS_T];
-    __shared__ int wsum[4];
     __shared__ int s_nan;
     const int b = blockIdx.x;
     const int R = min(counts[b], cap);
@@ -1075,7 +1077,7 @@ __global__ void __launch_bounds__(256) classify_regions_kernel(const long long *
     }
     if (threadIdx.x == 0) { s_particle = 0; s_nan = 0; }
     __syncthreads();
-    for (int r = threadIdx.x; r < R; r += 256) {
+    for (int r = threadIdx.x; r < R; r += CLS_THREADS) {
         int c = co[r];
         long long area = st[(int64_t)r * 8];
         int slot = tab.slot[c];
@@ -1098,7 +1100,7 @@ __global__ void __launch_bounds__(256) classify_regions_kernel(const long long *
     }
     __syncthreads();
     // cluster.cells = int(area // mean(cell areas))   (:776-781)
-    for (int r = threadIdx.x; r < R; r += 256) {
+    for (int r = threadIdx.x; r < R; r += CLS_THREADS) {
         if (kd[r] != 2) continue;
         int slot = so[r];
         if (s_ncell[slot] == 0) { cl[r] = -1; s_nan = 1; continue; }  // the reference raises ValueError here
@@ -1114,28 +1116,39 @@ __global__ void __launch_bounds__(256) classify_regions_kernel(const long long *
     }
     __syncthreads();
     int *lists = region_list + (int64_t)b * (CLS_T + 1) * cap;
-    for (int slot = 0; slot < tab.n_slots; ++slot) {
-        int carry_cell = 0, carry_clu = 0;
-        for (int base = 0; base < R; base += 256) {
-            int r = base + threadIdx.x;
-            int is_cell = (r < R && so[r] == slot && kd[r] == 1) ? 1 : 0;
-            int is_clu = (r < R && so[r] == slot && kd[r] == 2) ? 1 : 0;
-            int tot_cell, tot_clu;
-            int ex_cell = block_exclusive_scan256(is_cell, &tot_cell, wsum);
-            int ex_clu = block_exclusive_scan256(is_clu, &tot_clu, wsum);
-            if (is_cell) {
-                int pos = carry_cell + ex_cell;
-                lists[(int64_t)slot * cap + pos] = r;
-                lists[(int64_t)CLS_T * cap + s_base[slot] + pos] = r;
-            }
-            if (is_clu) {
-                int pos = s_ncell[slot] + carry_clu + ex_clu;
-                lists[(int64_t)slot * cap + pos] = r;
-                lists[(int64_t)CLS_T * cap + s_base[slot] + pos] = r;
-            }
-            carry_cell += tot_cell;
-            carry_clu += tot_clu;
+    // list positions: ONE pass over the regions for all (slot, kind) pairs.  A region belongs to at most one of the
+    // 2 * CLS_T lists, so its position is the number of earlier regions of the same list: per wave a ballot per list and a
+    // population count, across the waves one exchange through LDS per CLS_THREADS regions (it used to be a block scan with
+    // two barriers per list and per 256 regions)
+    __shared__ int s_wcount[CLS_THREADS / 64][2 * CLS_T];
+    __shared__ int s_carry[2 * CLS_T];
+    if (threadIdx.x < 2 * CLS_T) s_carry[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = 0; base < R; base += CLS_THREADS) {
+        const int r = base + threadIdx.x;
+        const int mine = (r < R && kd[r] != 0) ? (int)so[r] * 2 + (kd[r] - 1) : -1;  // list of this region (kind 1 or 2 has a slot)
+        int before = 0;
+#pragma unroll
+        for (int f = 0; f < 2 * CLS_T; ++f) {
+            const unsigned long long m = __ballot(mine == f);
+            if (mine == f) before = __popcll(m & below);
+            if (lane == 0) s_wcount[wid][f] = __popcll(m);
         }
+        __syncthreads();
+        if (mine >= 0) {
+            int pos = s_carry[mine] + before;
+            for (int w = 0; w < wid; ++w) pos += s_wcount[w][mine];
+            const int slot = mine >> 1;
+            if (mine & 1) pos += s_ncell[slot];  // a type's clusters follow its cells
+            lists[(int64_t)slot * cap + pos] = r;
+            lists[(int64_t)CLS_T * cap + s_base[slot] + pos] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * CLS_T)
+            for (int w = 0; w < CLS_THREADS / 64; ++w) s_carry[threadIdx.x] += s_wcount[w][threadIdx.x];
+        __syncthreads();
     }
     if (threadIdx.x < CLS_T) {
         int t = threadIdx.x;
@@ -1413,7 +1426,7 @@ int pcseg_classify_regions(const int64_t *stats, const uint8_t *cls_out, const i
         tab.min_cluster[t] = t < n_slots ? min_cluster[t] : 0x7FFFFFFF;
     }
     tab.n_slots = n_slots;
-    PCSEG_LAUNCH(classify_regions_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const long long *)stats, cls_out,
+    PCSEG_LAUNCH(classify_regions_kernel, dim3(B), dim3(CLS_THREADS), 0, (hipStream_t)stream, (const long long *)stats, cls_out,
                        counts, tab, kind, slot_of, cells, (long long *)particle_area, (long long *)type_stats, region_list, n_list,
                        nan_flag, cap);
     PCSEG_CHECK_LAUNCH();
