@@ -642,6 +642,34 @@ __global__ void __launch_bounds__(256) dilate_bits_kernel(const unsigned *__rest
     out[((int64_t)b * nch + ch) * W + c] = acc;
 }
 
+// disk(2) -- the only radius the reference dilates its masks with (tiff_analysis.py:829) -- with its eleven words
+// (columns c-2..c+2 of the row word, c-1..c+1 of the words above and below) as ONE batch of loads at clamped addresses;
+// the general kernel above tests every load and works the half widths out with a loop of multiplications per row offset
+// (59 us a launch for 6 M words).  Offsets: dy = 0: |dx| <= 2, |dy| = 1: |dx| <= 1, |dy| = 2: dx = 0.
+__global__ void __launch_bounds__(256) dilate_bits_disk2_kernel(const unsigned *__restrict__ in, unsigned *__restrict__ out, int H, int W,
+                                                                 int nch)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    if (c >= W) return;
+    const unsigned *base = in + (int64_t)b * nch * W;
+    const int chu = max(ch - 1, 0), chd = min(ch + 1, nch - 1);
+    const unsigned *rc = base + rowoff(ch, W), *ru = base + rowoff(chu, W), *rd = base + rowoff(chd, W);
+    const int c1l = max(c - 1, 0), c2l = max(c - 2, 0), c1r = min(c + 1, W - 1), c2r = min(c + 2, W - 1);
+    // (a clamped column repeats a word that is OR-ed in anyway: the OR does not change)
+    const unsigned w0 = rc[c], w1l = rc[c1l], w1r = rc[c1r], w2l = rc[c2l], w2r = rc[c2r];
+    unsigned u0 = ru[c], u1l = ru[c1l], u1r = ru[c1r], d0 = rd[c], d1l = rd[c1l], d1r = rd[c1r];
+    if (ch == 0) u0 = u1l = u1r = 0;          // outside the image = 0
+    if (ch + 1 >= nch) d0 = d1l = d1r = 0;
+    const unsigned cur1 = w0 | w1l | w1r, prev1 = u0 | u1l | u1r, next1 = d0 | d1l | d1r;
+    unsigned acc = cur1 | w2l | w2r;
+    acc |= (cur1 << 1) | (prev1 >> 31) | (cur1 >> 1) | (next1 << 31);
+    acc |= (w0 << 2) | (u0 >> 30) | (w0 >> 2) | (d0 << 30);
+    const int rows = min(32, H - ch * 32);
+    if (rows < 32) acc &= (1u << rows) - 1u;
+    out[((int64_t)b * nch + ch) * W + c] = acc;
+}
+
 // ---- components of a 1-bit image from its vertical runs (A6: label(dilated mask), tiff_analysis.py:829) ----------
 // The dilated masks of the merge step are only ever LOOKED UP at a few hundred centroid pixels per frame, so no label
 // image is made: the nodes of the union-find are the vertical runs of set bits (a run never leaves its 32-row word; it
@@ -1104,7 +1132,8 @@ int pcseg_dilate_ccl_roots_u8(const uint8_t *in, uint64_t value_bits, int radius
         PCSEG_LAUNCH(set_bits_kernel, g, dim3(256), 0, s, in, (unsigned long long)value_bits, bits, H, W, nch);
     }
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, dil, radius, H, W, nch);
+    if (radius == 2) PCSEG_LAUNCH(dilate_bits_disk2_kernel, g, dim3(256), 0, s, (const unsigned *)bits, dil, H, W, nch);
+    else PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, dil, radius, H, W, nch);
     PCSEG_CHECK_LAUNCH();
     return ccl_roots<KeyBits, true>(KeyBits{dil, W, nch}, roots, B, H, W, s);
 }
@@ -1137,7 +1166,8 @@ int pcseg_dilate_ccl_runs_u8(const uint8_t *in, uint64_t value_bits, int radius,
         PCSEG_LAUNCH(set_bits_kernel, g, dim3(256), 0, s, in, (unsigned long long)value_bits, bits, H, W, nch);
     }
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, (unsigned *)dilated_bits, radius, H, W, nch);
+    if (radius == 2) PCSEG_LAUNCH(dilate_bits_disk2_kernel, g, dim3(256), 0, s, (const unsigned *)bits, (unsigned *)dilated_bits, H, W, nch);
+    else PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, (unsigned *)dilated_bits, radius, H, W, nch);
     PCSEG_CHECK_LAUNCH();
     PCSEG_LAUNCH(bitrun_tile_kernel, dim3((W + BR_TW - 1) / BR_TW, (nch + BR_CH - 1) / BR_CH, B), dim3(256), 0, s,
                  (const unsigned *)dilated_bits, (int *)run_parent, H, W, nch);
@@ -1171,7 +1201,8 @@ int pcseg_dilate_ccl_runs_multi_u8(const uint8_t *in, const uint64_t *value_bits
     PCSEG_CHECK_LAUNCH();
     // everything behind the bit planes sees n_masks * B independent frames
     dim3 g((W + 255) / 256, nch, BM);
-    PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, (unsigned *)dilated_bits, radius, H, W, nch);
+    if (radius == 2) PCSEG_LAUNCH(dilate_bits_disk2_kernel, g, dim3(256), 0, s, (const unsigned *)bits, (unsigned *)dilated_bits, H, W, nch);
+    else PCSEG_LAUNCH(dilate_bits_kernel, g, dim3(256), 0, s, (const unsigned *)bits, (unsigned *)dilated_bits, radius, H, W, nch);
     PCSEG_CHECK_LAUNCH();
     PCSEG_LAUNCH(bitrun_tile_kernel, dim3((W + BR_TW - 1) / BR_TW, (nch + BR_CH - 1) / BR_CH, BM), dim3(256), 0, s,
                  (const unsigned *)dilated_bits, (int *)run_parent, H, W, nch);
