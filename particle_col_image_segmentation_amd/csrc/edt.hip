@@ -124,23 +124,42 @@ __global__ void __launch_bounds__(256) edt_carry_kernel(const unsigned *__restri
     const int64_t base = (int64_t)b * nch * W + c;
     bool has_zero = false;
     unsigned d = G_INF;  // distance from row (r0 - 1) ... tracked as "distance of first row of the word to the zero"
-    for (int ch = 0; c < W && ch < nch; ++ch) {
-        up[base + rowoff(ch, W)] = (uint16_t)d;
-        int rows = min(EDT_CH, H - ch * EDT_CH);
-        unsigned valid = rows == 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
-        unsigned zero = ~bits[base + rowoff(ch, W)] & valid;
-        if (zero) { d = rows - (31 - __clz(zero)); has_zero = true; }  // from first row of next word to the last zero of this word
-        else d = d == G_INF ? G_INF : d + rows;
+    // (the words of a column are loaded eight at a time -- the carry depends on the previous word, the LOADS do not; one
+    // load per step of the carry was a memory round trip per word with a quarter of the chip's wave slots in use)
+    constexpr int CB = 8;
+    for (int ch0 = 0; c < W && ch0 < nch; ch0 += CB) {
+        unsigned wv[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) wv[k] = bits[base + rowoff(min(ch0 + k, nch - 1), W)];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            const int ch = ch0 + k;
+            if (ch >= nch) break;
+            up[base + rowoff(ch, W)] = (uint16_t)d;
+            int rows = min(EDT_CH, H - ch * EDT_CH);
+            unsigned valid = rows == 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
+            unsigned zero = ~wv[k] & valid;
+            if (zero) { d = rows - (31 - __clz(zero)); has_zero = true; }  // from first row of next word to the last zero of this word
+            else d = d == G_INF ? G_INF : d + rows;
+        }
     }
     if (__syncthreads_or(has_zero) && threadIdx.x == 0) any_bg[b] = 1;
     d = G_INF;
-    for (int ch = nch - 1; c < W && ch >= 0; --ch) {
-        dn[base + rowoff(ch, W)] = (uint16_t)d;
-        int rows = min(EDT_CH, H - ch * EDT_CH);
-        unsigned valid = rows == 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
-        unsigned zero = ~bits[base + rowoff(ch, W)] & valid;
-        if (zero) d = (__ffs(zero) - 1) + 1;  // from last row of previous word to the first zero of this word
-        else d = d == G_INF ? G_INF : d + rows;
+    for (int ch0 = nch - 1; c < W && ch0 >= 0; ch0 -= CB) {
+        unsigned wv[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) wv[k] = bits[base + rowoff(max(ch0 - k, 0), W)];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            const int ch = ch0 - k;
+            if (ch < 0) break;
+            dn[base + rowoff(ch, W)] = (uint16_t)d;
+            int rows = min(EDT_CH, H - ch * EDT_CH);
+            unsigned valid = rows == 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
+            unsigned zero = ~wv[k] & valid;
+            if (zero) d = (__ffs(zero) - 1) + 1;  // from last row of previous word to the first zero of this word
+            else d = d == G_INF ? G_INF : d + rows;
+        }
     }
 }
 
