@@ -319,6 +319,39 @@ __device__ __forceinline__ int relabel_decode(const int *par, int *lab, const in
     return v;
 }
 
+// NCH chains in lockstep: root[q] (-1 = none) walks to its root, val[q] becomes the root's decoded label
+template <typename Pred, int NCH>
+__device__ __forceinline__ void relabel_chains(const int *par, int *lab, const int *blockoff, const Pred &pred, int b, int64_t n, int nblk,
+                                               bool chase, int (&root)[NCH], int (&val)[NCH])
+{
+    if (chase) {
+        bool more = true;
+        while (more) {
+            int nx[NCH];
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) nx[q] = root[q] >= 0 ? par[root[q]] : -1;
+            more = false;
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                more = more || nx[q] != root[q];
+                root[q] = nx[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        val[q] = 0;
+        if (root[q] >= 0 && pred((int64_t)b * n + root[q]))
+            val[q] = __hip_atomic_load(lab + root[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // rank code or final label
+    }
+    int off[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) off[q] = val[q] < 0 ? blockoff[b * nblk + root[q] / SCAN_PIX] : 0;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q)
+        if (val[q] < 0) val[q] = off[q] - val[q];
+}
+
 template <typename Pred>
 __global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
                                                                  Pred pred, int64_t n, int nblk, bool chase)
@@ -333,47 +366,42 @@ __global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__res
         const int64_t i = i0 + (int64_t)q * SCAN_PIX;
         pq[q] = i < n ? *reinterpret_cast<const int4 *>(par + i) : make_int4(-1, -1, -1, -1);
     }
-    // neighbouring lanes mostly carry the same entry too: only the first lane of each run of equal entries walks (a gather
-    // costs the texture addresser by its active lanes), the others take its answer with one cross-lane read
-    int lead[RELABEL_Q], root[RELABEL_Q], val[RELABEL_Q], head_lane[RELABEL_Q];
+    // First batch: the quads' first entries.  Neighbouring lanes mostly carry the same entry: only the first lane of each
+    // run of equal entries walks, the others take its answer with one cross-lane read.
+    // Second batch: a quad that straddles a component border holds a second entry.  Walked one pixel at a time these were
+    // most of the pass (a copy of the two images takes 100 us, the pass without its gathers took 224): up to twelve
+    // dependent chains per lane, taken by the whole wave whenever one of its 256 pixels sat at a border.
+    // (all eight chains in ONE lockstep loop: 209 us against 182 for the two batches -- a wave without a border quad skips
+    // the second batch altogether; the watershed's label pass, where borders are everywhere, is the other way round)
+    int lead[RELABEL_Q], lead2[RELABEL_Q], root[RELABEL_Q], val[RELABEL_Q], val2[RELABEL_Q], head_lane[RELABEL_Q];
+    bool third = false;  // a quad with three different entries: its odd pixels walk on their own below
     const int lane = lane_id();
 #pragma unroll
     for (int q = 0; q < RELABEL_Q; ++q) {
-        lead[q] = pq[q].x >= 0 ? pq[q].x : (pq[q].y >= 0 ? pq[q].y : (pq[q].z >= 0 ? pq[q].z : pq[q].w));
+        const int pv[4] = {pq[q].x, pq[q].y, pq[q].z, pq[q].w};
+        lead[q] = pv[0] >= 0 ? pv[0] : (pv[1] >= 0 ? pv[1] : (pv[2] >= 0 ? pv[2] : pv[3]));
         const int left = __shfl_up(lead[q], 1);
         const bool head = lane == 0 || lead[q] != left;
         const unsigned long long heads = __ballot(head);
         head_lane[q] = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
         root[q] = head ? lead[q] : -1;
-    }
-    if (chase) {
-        bool more = true;
-        while (more) {
-            int nx[RELABEL_Q];
+        lead2[q] = -1;
 #pragma unroll
-            for (int q = 0; q < RELABEL_Q; ++q) nx[q] = root[q] >= 0 ? par[root[q]] : -1;
-            more = false;
-#pragma unroll
-            for (int q = 0; q < RELABEL_Q; ++q) {
-                more = more || nx[q] != root[q];
-                root[q] = nx[q];
-            }
+        for (int j = 1; j < 4; ++j) {
+            if (pv[j] < 0 || pv[j] == lead[q]) continue;
+            if (lead2[q] < 0) lead2[q] = pv[j];
+            else if (pv[j] != lead2[q]) third = true;
         }
     }
+    relabel_chains(par, lab, blockoff, pred, b, n, nblk, chase, root, val);
+    bool any2 = false;
 #pragma unroll
     for (int q = 0; q < RELABEL_Q; ++q) {
-        val[q] = 0;
-        if (root[q] >= 0 && pred((int64_t)b * n + root[q]))
-            val[q] = __hip_atomic_load(lab + root[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    int off[RELABEL_Q];
-#pragma unroll
-    for (int q = 0; q < RELABEL_Q; ++q) off[q] = val[q] < 0 ? blockoff[b * nblk + root[q] / SCAN_PIX] : 0;
-#pragma unroll
-    for (int q = 0; q < RELABEL_Q; ++q) {
-        if (val[q] < 0) val[q] = off[q] - val[q];
         val[q] = __shfl(val[q], head_lane[q]);
+        root[q] = lead2[q];
+        any2 = any2 || lead2[q] >= 0;
     }
+    if (__any(any2)) relabel_chains(par, lab, blockoff, pred, b, n, nblk, chase, root, val2);
 #pragma unroll
     for (int q = 0; q < RELABEL_Q; ++q) {
         const int64_t i = i0 + (int64_t)q * SCAN_PIX;
@@ -384,7 +412,9 @@ __global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__res
         for (int j = 0; j < 4; ++j) {
             out[j] = 0;
             if (pv[j] < 0) continue;
-            out[j] = pv[j] == lead[q] ? val[q] : relabel_decode(par, lab, blockoff, pred, b, n, nblk, pv[j], chase);
+            if (pv[j] == lead[q]) out[j] = val[q];
+            else if (pv[j] == lead2[q]) out[j] = val2[q];
+            else if (third) out[j] = relabel_decode(par, lab, blockoff, pred, b, n, nblk, pv[j], chase);
         }
         *reinterpret_cast<int4 *>(lab + i) = make_int4(out[0], out[1], out[2], out[3]);
     }

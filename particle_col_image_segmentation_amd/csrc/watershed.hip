@@ -1015,6 +1015,27 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
 // first reachable pixel; a pixel with another parent entry walks on its own afterwards.
 constexpr int LABEL4_Q = 4;
 
+// NCH chains in lockstep: root[q] (-1 = none) walks to its root, lab[q] becomes the root's label (0: no seed)
+template <int NCH>
+__device__ __forceinline__ void label4_chains(const int *par, const int *F, int64_t fbase, int (&root)[NCH], int (&lab)[NCH])
+{
+    bool more = true;
+    while (more) {
+        int nx[NCH];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) nx[q] = root[q] >= 0 ? par[root[q] & (UF_NS - 1)] : -1;
+        more = false;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            more = more || nx[q] != root[q];
+            root[q] = nx[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NCH; ++q)
+        lab[q] = (root[q] >= 0 && root[q] < UF_NS) ? F[fbase + root[q]] : 0;  // roots are labelled pixels, never changed by this pass
+}
+
 __global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ minmask,
                                                             int *F, uint8_t *__restrict__ bad, int *__restrict__ tie_flags,
                                                             int64_t n)
@@ -1031,65 +1052,79 @@ __global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict
         p4[q] = i < n ? *reinterpret_cast<const int4 *>(par + i) : make_int4(-1, -1, -1, -1);
         m4[q] = i < n ? *reinterpret_cast<const unsigned *>(minmask + fbase + i) : 0u;
     }
-    // (only the first lane of each run of lanes with the same entry walks; the others read its answer across lanes)
-    int lead[LABEL4_Q], root[LABEL4_Q], lab[LABEL4_Q], head_lane[LABEL4_Q];
+    // the labels of the quads that hold a seed (reachable pixel with an empty minimum-neighbour mask), as one batch
+    unsigned seeds[LABEL4_Q];
+    int4 f4[LABEL4_Q];
+#pragma unroll
+    for (int q = 0; q < LABEL4_Q; ++q) {
+        const int pv[4] = {p4[q].x, p4[q].y, p4[q].z, p4[q].w};
+        seeds[q] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (pv[j] >= 0 && ((m4[q] >> (8 * j)) & 255u) == 0) seeds[q] |= 1u << j;
+        f4[q] = make_int4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < LABEL4_Q; ++q)
+        if (seeds[q]) f4[q] = *reinterpret_cast<const int4 *>(F + fbase + i0 + q * 1024);
+    // chains 0..3: the quads' first entries (only the first lane of each run of lanes with the same entry walks; the others
+    // read its answer across lanes); chains 4..7: the second entry of quads that straddle two components (walked pixel by
+    // pixel these were most of the pass: see ccl_relabel_quads_kernel).  All eight advance in lockstep.
+    int lead[LABEL4_Q], lead2[LABEL4_Q], rt[2 * LABEL4_Q], lb[2 * LABEL4_Q], head_lane[LABEL4_Q];
     const int lane = lane_id();
 #pragma unroll
     for (int q = 0; q < LABEL4_Q; ++q) {
-        lead[q] = p4[q].x >= 0 ? p4[q].x : (p4[q].y >= 0 ? p4[q].y : (p4[q].z >= 0 ? p4[q].z : p4[q].w));
+        const int pv[4] = {p4[q].x, p4[q].y, p4[q].z, p4[q].w};
+        lead[q] = pv[0] >= 0 ? pv[0] : (pv[1] >= 0 ? pv[1] : (pv[2] >= 0 ? pv[2] : pv[3]));
         const int left = __shfl_up(lead[q], 1);
         const bool head = lane == 0 || lead[q] != left;
         const unsigned long long heads = __ballot(head);
         head_lane[q] = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
-        root[q] = head ? lead[q] : -1;
+        rt[q] = head ? lead[q] : -1;
+        lead2[q] = -1;
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (pv[j] >= 0 && pv[j] != lead[q] && lead2[q] < 0) lead2[q] = pv[j];
+        rt[LABEL4_Q + q] = lead2[q];
     }
-    bool more = true;
-    while (more) {
-        int nx[LABEL4_Q];
-#pragma unroll
-        for (int q = 0; q < LABEL4_Q; ++q) nx[q] = root[q] >= 0 ? par[root[q] & (UF_NS - 1)] : -1;
-        more = false;
-#pragma unroll
-        for (int q = 0; q < LABEL4_Q; ++q) {
-            more = more || nx[q] != root[q];
-            root[q] = nx[q];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < LABEL4_Q; ++q)
-        lab[q] = (root[q] >= 0 && root[q] < UF_NS) ? F[fbase + root[q]] : 0;  // roots are labelled pixels, never changed by this pass
+    label4_chains(par, F, fbase, rt, lb);
+    int root[LABEL4_Q], lab[LABEL4_Q], root2[LABEL4_Q], lab2[LABEL4_Q];
 #pragma unroll
     for (int q = 0; q < LABEL4_Q; ++q) {
-        root[q] = __shfl(root[q], head_lane[q]);
-        lab[q] = __shfl(lab[q], head_lane[q]);
+        root[q] = __shfl(rt[q], head_lane[q]);
+        lab[q] = __shfl(lb[q], head_lane[q]);
+        root2[q] = rt[LABEL4_Q + q];
+        lab2[q] = lb[LABEL4_Q + q];
     }
 #pragma unroll
     for (int q = 0; q < LABEL4_Q; ++q) {
         const int64_t i = i0 + q * 1024;
         if (i >= n) continue;
         const int pv[4] = {p4[q].x, p4[q].y, p4[q].z, p4[q].w};
+        const int sv[4] = {f4[q].x, f4[q].y, f4[q].z, f4[q].w};
         int fv[4] = {0, 0, 0, 0};  // unreachable pixels and pixels of components without a seed stay unlabelled
-        int last_p = lead[q], last_root = root[q], last_lab = lab[q];
         bool wrote = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int x = pv[j];
             if (x < 0) continue;
-            const bool seed = ((m4[q] >> (8 * j)) & 255u) == 0;
-            if (seed) fv[j] = F[fbase + i + j];
-            if (x != last_p) {
-                last_p = x;
+            const bool seed = (seeds[q] >> j) & 1u;
+            if (seed) fv[j] = sv[j];
+            int x_root, x_lab;
+            if (x == lead[q]) { x_root = root[q]; x_lab = lab[q]; }
+            else if (x == lead2[q]) { x_root = root2[q]; x_lab = lab2[q]; }
+            else {  // (third: a quad with three different entries)
                 int t;
                 while ((t = par[x & (UF_NS - 1)]) != x) x = t;
-                last_root = x;
-                last_lab = x < UF_NS ? F[fbase + x] : 0;
+                x_root = x;
+                x_lab = x < UF_NS ? F[fbase + x] : 0;
             }
-            if (last_root >= UF_NS) continue;  // no labelled pixel in the component
+            if (x_root >= UF_NS) continue;  // no labelled pixel in the component
             if (!seed) {
-                fv[j] = last_lab;
+                fv[j] = x_lab;
                 wrote = true;
-            } else if (fv[j] != last_lab) {
-                bad[fbase + last_root] = 1;
+            } else if (fv[j] != x_lab) {
+                bad[fbase + x_root] = 1;
                 if (tie_flags[b] == 0) tie_flags[b] = 1;
             }
         }
