@@ -162,7 +162,9 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
             res, rid = pending.popleft()
             take(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
         pending.append((pipe.run(frames), ids))
-        if len(pending) > depth:
+        # ... and the tables of every batch that has finished meanwhile are taken right away (in order): what is left
+        # to drain after the last batch is then only what is still running
+        while pending and (len(pending) > depth or (len(pending) > 1 and getattr(pending[0][0], "ready", lambda: False)())):
             res, rid = pending.popleft()
             take(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
     while pending:

@@ -51,6 +51,20 @@ class BatchResult(dict):
             return list(pending.result()[1])
         return list(pending)
 
+    def ready(self):
+        """True once the batch's kernel chains have finished (never blocks: a batch whose lane has not even enqueued it
+        yet is not ready)."""
+        pending = self._pending
+        if pending is None:
+            return True
+        if hasattr(pending, "result"):
+            if not pending.done():
+                return False
+            events = pending.result()[1]
+        else:
+            events = pending
+        return all(ev.query() for ev in events)
+
     def synchronize(self):
         self._check_alive()
         pending = self._pending
