@@ -813,8 +813,10 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
         if (r < H && c < W) {
             minmask[fbase + rowoff(r, W) + c] = m8;
             // the "component cannot be resolved" marks of this level start clear: every root the label passes will look at
-            // lies in a tile this pass visits (instead of a memset of the whole array per level)
-            bad[fbase + rowoff(r, W) + c] = 0;
+            // lies in a tile this pass visits (instead of a memset of the whole array per level) -- and is a labelled
+            // pixel (roots are minima of the virtual order, in which labelled pixels come first; a component without one
+            // is never marked): only those bytes are written, a few thousand a frame instead of every pixel's
+            if (fv[k] != 0) bad[fbase + rowoff(r, W) + c] = 0;
         }
     }
     __syncthreads();
