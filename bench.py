@@ -183,12 +183,18 @@ def secondary_leg(args, stack, cell_types, pipe):
     repeated), i.e. several frames per CU.  Two of its frames are checked against the oracle."""
     import torch
     from oracle import parity
+    import gc
     B0 = stack.shape[0]
     reps = max(1, args.secondary_batch // B0)
+    # everything the earlier legs still hold goes back to the driver BEFORE the 160 GB of this leg are allocated: the flood
+    # is a latency-bound random walk over its heaps, and with the card's memory carved up by what earlier legs left behind
+    # (captured graphs' pools, cached blocks) the same batch measured 215-250 Mpixels/s instead of 490 -- same kernels,
+    # same results; with the other legs switched off it is 488-490 every time
+    pipe.synchronize()
+    gc.collect()
+    torch.cuda.empty_cache()
     big = stack.repeat(reps, 1, 1, 1)
     n, H, W = big.shape[0], big.shape[2], big.shape[3]
-    pipe.synchronize()
-    torch.cuda.empty_cache()   # the headline legs' cached blocks: this batch wants most of the card
     solo = type(pipe)(cell_types, lanes=1)
     res = solo.run(big)        # allocator priming on the tie-free frames (same sizes, milliseconds)
     res.synchronize()
