@@ -55,6 +55,10 @@ __device__ __forceinline__ void ccl_tile_unions(const int *key, int *par)
 {
     for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
         const int k = key[i], lc = i % CCL_TW;
+        if (__ballot(k != 0) == 0) {  // a tile row without a foreground pixel (sparse keys: the local-maxima candidates)
+            par[i] = -1;
+            continue;
+        }
         const bool head = lc == 0 || key[i - 1] != k;
         const unsigned long long heads = __ballot(head);
         const unsigned long long upto = heads & (lc == 63 ? ~0ull : ((2ull << lc) - 1ull));
