@@ -891,7 +891,32 @@ __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__res
     const TileIndex ti = xcd_tile_index();
     const int r0 = ti.y * LM_TH, c0 = ti.x * LM_TW;
     const int64_t fbase = (int64_t)ti.z * H * W;
-    {
+    if ((W & 3) == 0 && c0 + LM_TW <= W && (((uintptr_t)img) & 15) == 0) {
+        // full-width tile of a frame with 16-byte aligned rows: the 64 interior columns of the 36 rows as 16-byte quads
+        // (three trips), the four halo columns as one scalar trip -- all of them one batch of loads at clamped addresses
+        constexpr int QUADS = LM_SH * (LM_TW / 4), TRIPS = (QUADS + 255) / 256;
+        int4 tq[TRIPS];
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = min((int)threadIdx.x + 256 * t, QUADS - 1);
+            const int r = r0 + i / (LM_TW / 4) - 2;
+            tq[t] = *reinterpret_cast<const int4 *>(img + fbase + rowoff(min(max(r, 0), H - 1), W) + c0 + 4 * (i % (LM_TW / 4)));
+        }
+        const int hl = min((int)threadIdx.x, LM_SH * 4 - 1);
+        const int hr = r0 + (hl >> 2) - 2, hx = (hl & 3) < 2 ? (hl & 3) - 2 : LM_TW + (hl & 3) - 2, hc = c0 + hx;
+        const int hv = img[fbase + rowoff(min(max(hr, 0), H - 1), W) + min(max(hc, 0), W - 1)];
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = (int)threadIdx.x + 256 * t;
+            if (i < QUADS) {
+                const int lr = i / (LM_TW / 4), r = r0 + lr - 2;
+                const bool in = r >= 0 && r < H;
+                int *dst = tile + lr * LM_SW + 2 + 4 * (i % (LM_TW / 4));
+                dst[0] = in ? tq[t].x : OUTSIDE; dst[1] = in ? tq[t].y : OUTSIDE; dst[2] = in ? tq[t].z : OUTSIDE; dst[3] = in ? tq[t].w : OUTSIDE;
+            }
+        }
+        if (threadIdx.x < LM_SH * 4) tile[(hl >> 2) * LM_SW + hx + 2] = (hr >= 0 && hr < H && hc >= 0 && hc < W) ? hv : OUTSIDE;
+    } else {
         // one batch of loads instead of a loop of round trips (clamped addresses, no branch around the loads)
         constexpr int TRIPS = (LM_SH * LM_SW + 255) / 256;
         int tv[TRIPS];
