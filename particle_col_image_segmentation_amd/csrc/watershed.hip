@@ -764,7 +764,33 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
     const int r0 = tile_y * UF_TH, c0 = tile_x * UF_TW;
     if (!ws_active(active, b, r0, c0, tilesX, tilesY)) return;  // UF tiles (64x32) nest inside the 64x64 tiles
     const int64_t fbase = (int64_t)b * H * W;
-    {
+    if (sizeof(KeyT) == 4 && (W & 3) == 0 && c0 + UF_TW <= W && (((uintptr_t)K) & 15) == 0) {
+        // full-width tile, 4-byte keys, 16-byte aligned rows: the 64 interior columns of the 34 rows as 16-byte quads (three
+        // trips instead of nine), the two halo columns as one scalar trip; clamped addresses, one batch of loads
+        constexpr int QUADS = UF_SH * (UF_TW / 4), TRIPS = (QUADS + 255) / 256;
+        uint4 kq[TRIPS];
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = min((int)threadIdx.x + 256 * t, QUADS - 1);
+            const int r = r0 + i / (UF_TW / 4) - 1;
+            kq[t] = *reinterpret_cast<const uint4 *>(K + fbase + rowoff(min(max(r, 0), H - 1), W) + c0 + 4 * (i % (UF_TW / 4)));
+        }
+        const int hl = min((int)threadIdx.x, UF_SH * 2 - 1);
+        const int hr = r0 + (hl >> 1) - 1, hx = (hl & 1) ? UF_TW : -1, hc = c0 + hx;
+        const KeyT hv = K[fbase + rowoff(min(max(hr, 0), H - 1), W) + min(max(hc, 0), W - 1)];
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = (int)threadIdx.x + 256 * t;
+            if (i < QUADS) {
+                const int lr = i / (UF_TW / 4), r = r0 + lr - 1;
+                const bool in = r >= 0 && r < H;
+                KeyT *dst = sK + lr * UF_SW + 1 + 4 * (i % (UF_TW / 4));
+                dst[0] = in ? (KeyT)kq[t].x : KINF; dst[1] = in ? (KeyT)kq[t].y : KINF;
+                dst[2] = in ? (KeyT)kq[t].z : KINF; dst[3] = in ? (KeyT)kq[t].w : KINF;
+            }
+        }
+        if (threadIdx.x < UF_SH * 2) sK[(hl >> 1) * UF_SW + hx + 1] = (hr >= 0 && hr < H && hc >= 0 && hc < W) ? hv : KINF;
+    } else {
         // one batch of loads, not a loop of round trips: clamped (always valid) addresses, no branch around the loads,
         // out-of-frame cells fixed up by a select (see ws_relax_tile)
         constexpr int TRIPS = (UF_SH * UF_SW + 255) / 256;
