@@ -561,10 +561,18 @@ __global__ void __launch_bounds__(256, 4) region_stats_col_kernel(const int *__r
             if (q[j].label > 0) run_commit(ls, gst, overflow, b, cap, q[j]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
+    // flush: EIGHT LANES PER SLOT, one per column of the table row, so that one atomic instruction carries up to eight
+    // neighbouring 8-byte words of a row's 64-byte line (the three adds, the three mins, the two maxes) instead of 64 lanes
+    // aiming at 64 different lines eight times over
+    for (int base = 0; base < RED_SLOTS; base += 32) {
+        const int i = base + (int)(threadIdx.x >> 3), f = threadIdx.x & 7;
         const int l = tags[i];
         if (l == 0) continue;
-        region_slots_flush(lstat[i], gst + (int64_t)(l - 1) * 8);
+        long long *t = gst + (int64_t)(l - 1) * 8 + f;
+        const int v = lstat[i][f];
+        if (f < 3) atomicAdd((unsigned long long *)t, (unsigned long long)(unsigned)v);
+        else if (f == 5 || f == 6) atomic_max_i64(t, (long long)v);
+        else atomic_min_i64(t, (long long)v);
     }
 }
 
