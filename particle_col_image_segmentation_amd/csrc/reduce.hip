@@ -739,16 +739,15 @@ __global__ void __launch_bounds__(256, (NC <= 5 && !STATS_B) ? 3 : 2) region_sum
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
+    // flush: eight lanes per slot, one per plane, so that one atomic instruction carries a row's neighbouring sums (merged per
+    // 64-byte line by the hardware) instead of 64 lanes aiming at 64 different rows once per plane
+    static_assert(RED_MAXC == 8, "eight lanes per slot");
+    for (int base = 0; base < RED_SLOTS; base += 32) {
+        const int i = base + (int)(threadIdx.x >> 3), k = threadIdx.x & 7;
         const int l1 = tags_a[i], l2 = tags_b[i];
-        if (l1)
-            for (int k = 0; k < C; ++k)
-                if (lsum_a[i][k] != 0.0) atomicAdd(&ga[(int64_t)(l1 - 1) * C + k], lsum_a[i][k]);
-        if (l2) {
-            for (int k = 0; k < C; ++k)
-                if (lsum_b[i][k] != 0.0) atomicAdd(&gb[(int64_t)(l2 - 1) * C + k], lsum_b[i][k]);
-            if (STATS_B) region_slots_flush(lstat_b[i], gst_b + (int64_t)(l2 - 1) * 8);
-        }
+        if (l1 && k < C && lsum_a[i][k] != 0.0) atomicAdd(&ga[(int64_t)(l1 - 1) * C + k], lsum_a[i][k]);
+        if (l2 && k < C && lsum_b[i][k] != 0.0) atomicAdd(&gb[(int64_t)(l2 - 1) * C + k], lsum_b[i][k]);
+        if (STATS_B && l2 && k == 0) region_slots_flush(lstat_b[i], gst_b + (int64_t)(l2 - 1) * 8);
     }
 }
 
