@@ -1011,21 +1011,20 @@ __global__ void __launch_bounds__(MG_THREADS) merge_fused_kernel(const unsigned 
     }
     __syncthreads();  // (group ids and the zeroed rows of this block's groups: written above, used below by the same block)
     // (4) members take their leader's id; every listed region adds itself to its group's row (tiff_analysis.py:855-872)
-    for (int k = threadIdx.x; k < R; k += MG_THREADS) {
+    // (eight lanes per member, one per column of the row: the reads are one 64-byte line per member and the atomics of an
+    // instruction that fall into one line travel together -- see region_stats_col_kernel's flush)
+    for (int idx = threadIdx.x; idx < R * 8; idx += MG_THREADS) {
+        const int k = idx >> 3, f = idx & 7;
         int g = 0;
         if (key[k] < 0) g = gid[-key[k] - 1];
-        gof[k] = g;
+        if (f == 0) gof[k] = g;
         if (g <= 0) continue;
-        const long long *sr = st + (int64_t)lst[k] * 8;
-        long long *t = gs + (int64_t)(g - 1) * 8;
-        atomicAdd((unsigned long long *)&t[0], (unsigned long long)sr[0]);
-        atomicAdd((unsigned long long *)&t[1], (unsigned long long)sr[1]);
-        atomicAdd((unsigned long long *)&t[2], (unsigned long long)sr[2]);
-        atomicMin(&t[3], sr[3]);
-        atomicMin(&t[4], sr[4]);
-        atomicMax(&t[5], sr[5]);
-        atomicMax(&t[6], sr[6]);
-        atomicAdd((unsigned long long *)&t[7], 1ull);
+        const long long v = st[(int64_t)lst[k] * 8 + f];
+        long long *t = gs + (int64_t)(g - 1) * 8 + f;
+        if (f < 3) atomicAdd((unsigned long long *)t, (unsigned long long)v);
+        else if (f < 5) atomicMin(t, v);
+        else if (f < 7) atomicMax(t, v);
+        else atomicAdd((unsigned long long *)t, 1ull);
     }
     if (threadIdx.x == 0) n_groups[b] = carry;
 }
