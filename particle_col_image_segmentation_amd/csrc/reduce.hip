@@ -18,17 +18,18 @@ constexpr int RED_ROWS = 16;  // rows per block
 __device__ __forceinline__ void atomic_min_i64(long long *p, long long v) { atomicMin(p, v); }
 __device__ __forceinline__ void atomic_max_i64(long long *p, long long v) { atomicMax(p, v); }
 
+// (eight lanes per table row, one per column: a store instruction then covers eight whole 64-byte rows instead of one word
+// of 64 different rows)
 __global__ void __launch_bounds__(256) region_init_kernel(long long *__restrict__ stats, double *__restrict__ sums,
                                                            const int *__restrict__ counts, int cap, int C, int H, int W)
 {
     const int b = blockIdx.y;
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = idx >> 3, f = idx & 7;
     int nl = counts ? min(counts[b], cap) : cap;
     if (l >= nl) return;
-    long long *t = stats + ((int64_t)b * cap + l) * 8;
-    t[0] = 0; t[1] = 0; t[2] = 0; t[3] = H; t[4] = W; t[5] = 0; t[6] = 0; t[7] = 0x7FFFFFFFFFFFFFFFLL;
-    if (sums)
-        for (int k = 0; k < C; ++k) sums[((int64_t)b * cap + l) * C + k] = 0.0;
+    stats[((int64_t)b * cap + l) * 8 + f] = f == 3 ? (long long)H : (f == 4 ? (long long)W : (f == 7 ? 0x7FFFFFFFFFFFFFFFLL : 0LL));
+    if (sums && f < C) sums[((int64_t)b * cap + l) * C + f] = 0.0;
 }
 
 template <bool HAS_PLANES>
@@ -1245,7 +1246,7 @@ int pcseg_region_reduce_sel(const int32_t *labels, const int32_t *counts, const 
     PCSEG_REQUIRE(!cls || cls_out, "cls needs cls_out");
     hipStream_t s = (hipStream_t)stream;
     if (overflow) PCSEG_CHECK_HIP(hipMemsetAsync(overflow, 0, sizeof(int32_t) * B, s));
-    dim3 gi((cap + 255) / 256, B);
+    dim3 gi((cap * 8 + 255) / 256, B);  // eight lanes per row
     PCSEG_LAUNCH(region_init_kernel, gi, dim3(256), 0, s, (long long *)stats, sums, counts, cap, C, H, W);
     PCSEG_CHECK_LAUNCH();
     dim3 grid((H + RED_ROWS - 1) / RED_ROWS, B);
@@ -1288,7 +1289,8 @@ int pcseg_region_init(const int32_t *counts, int cap, int C, int B, int H, int W
     PCSEG_REQUIRE(stats && cap >= 1 && C >= 0 && C <= RED_MAXC && (C == 0 || sums) && check_shape(B, H, W), "bad arguments (C <= 8)");
     hipStream_t s = (hipStream_t)stream;
     if (overflow) PCSEG_CHECK_HIP(hipMemsetAsync(overflow, 0, sizeof(int32_t) * B, s));
-    PCSEG_LAUNCH(region_init_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, s, (long long *)stats, C ? sums : nullptr, counts, cap, C, H, W);
+    static_assert(RED_MAXC <= 8, "region_init_kernel has eight lanes per row");
+    PCSEG_LAUNCH(region_init_kernel, dim3((cap * 8 + 255) / 256, B), dim3(256), 0, s, (long long *)stats, C ? sums : nullptr, counts, cap, C, H, W);
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
 }
