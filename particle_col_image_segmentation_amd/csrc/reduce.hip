@@ -414,12 +414,17 @@ __global__ void __launch_bounds__(256, NC > 0 ? PCSEG_RED_WAVES : 4) region_redu
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
+    // flush, eight lanes per slot (see region_stats_col_kernel): one per column of the integer row, one per plane sum
+    for (int base = 0; base < RED_SLOTS; base += 32) {
+        const int i = base + (int)(threadIdx.x >> 3), f = threadIdx.x & 7;
         const int l = tags[i];
         if (l == 0) continue;
-        region_slots_flush(lstat[i], gst + (int64_t)(l - 1) * 8);
-        if (NC > 0)
-            for (int k = 0; k < C; ++k) atomicAdd(&gsum[(int64_t)(l - 1) * C + k], lsum[i][k]);
+        long long *t = gst + (int64_t)(l - 1) * 8 + f;
+        const int v = lstat[i][f];
+        if (f < 3) atomicAdd((unsigned long long *)t, (unsigned long long)(unsigned)v);
+        else if (f == 5 || f == 6) atomic_max_i64(t, (long long)v);
+        else atomic_min_i64(t, (long long)v);
+        if (NC > 0 && f < C) atomicAdd(&gsum[(int64_t)(l - 1) * C + f], lsum[i][f]);
     }
 }
 
