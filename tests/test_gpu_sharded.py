@@ -120,3 +120,25 @@ def test_sharded_fixture_is_what_the_pipeline_produces():
         np.testing.assert_allclose(drow[:, 2], exp, rtol=1e-12, atol=0)
         n_dist += len(drow)
     assert n_dist > 20
+
+
+@pytest.mark.gpu
+def test_host_rows_stream_and_regrow():
+    """One rank's table rows go to pinned host memory batch by batch (distributed._HostRows); a table that outgrows the
+    buffer sized from the first batch moves to a bigger one without losing rows."""
+    import torch
+    from particle_col_image_segmentation_amd.distributed import _HostRows
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(7)
+    parts = []
+    for n in (3, 5000, 0, 20000, 17):  # the first batch (3 rows) sizes the buffers: the later ones force two moves
+        parts.append({"rois": torch.rand((n, 12), generator=g, dtype=torch.float64).to(dev),
+                      "cells": torch.rand((n // 2, 21), generator=g, dtype=torch.float64).to(dev)})
+    rows = _HostRows(dev, expected_batches=1)
+    for p in parts:
+        rows.append(p)
+    out = rows.finish()
+    for k in ("rois", "cells"):
+        want = torch.cat([p[k] for p in parts]).cpu().numpy()
+        assert out[k].shape == want.shape
+        assert np.array_equal(out[k], want)
