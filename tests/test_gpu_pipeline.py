@@ -222,3 +222,20 @@ def test_graph_mode_replays_equal_eager_runs():
         results[0]["labels"]
     results[-1]["labels"]  # the newest result of each lane is still readable
     results[-2]["labels"]
+
+
+def test_batch_result_ready_never_blocks_and_turns_true():
+    """BatchResult.ready() is the non-blocking twin of synchronize(): False or True while the batch runs, True once it has
+    been waited for (run_sharded uses it to take finished batches' tables early)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from particle_col_image_segmentation_amd import synth
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline
+    dev = torch.device("cuda:0")
+    stack = synth.gen_batch_torch(4242, 2, 128, 128, dev)
+    pipe = FramePipeline(dict(synth.CELL_TYPES_5))
+    res = pipe.run(stack)
+    assert res.ready() in (False, True)
+    res.synchronize()
+    assert res.ready() is True
+    assert int(res["counts"].shape[0]) == 2
