@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(KeyFn keyfn, int *__restr
 // each with a chain of dependent finds): first the rows that start a tile row, lanes along the row; then, for every
 // other row, the columns either side of a vertical tile edge, lanes along the column.
 template <typename KeyFn, bool CONN8>
-__global__ void __launch_bounds__(256) ccl_border_kernel(KeyFn keyfn, int *__restrict__ parent, int H, int W)
+__global__ void __launch_bounds__(256) ccl_border_kernel(KeyFn keyfn, int *__restrict__ parent, int H, int W, int *__restrict__ corrupt)
 {
     const int n_top_rows = (H - 1) / CCL_TH, n_edges = (W - 1) / CCL_TW;
     const int n_cols = CONN8 ? 2 * n_edges : n_edges;
@@ -145,12 +145,13 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(KeyFn keyfn, int *__res
     const bool nw_same = r > 0 && c > 0 && k_nw == k;
     // (at a tile corner both the W and the N link cross tiles and would justify each other: keep both there)
     const bool corner = top && left;
-    if (left && w_same && (corner || !(n_same && nw_same))) unite_glb(par, p, p - 1);
+    int *bad = corrupt ? corrupt + b : nullptr;  // raised by a fenced walk (common.h, walk_ok)
+    if (left && w_same && (corner || !(n_same && nw_same))) unite_glb(par, p, p - 1, bad);
     if (r > 0) {
-        if (top && n_same && (corner || !(w_same && nw_same))) unite_glb(par, p, p - W);
+        if (top && n_same && (corner || !(w_same && nw_same))) unite_glb(par, p, p - W, bad);
         if (CONN8) {
-            if ((top || left) && nw_same && !n_same && !w_same) unite_glb(par, p, p - W - 1);
-            if (c + 1 < W && (top || right) && !n_same && k_ne == k) unite_glb(par, p, p - W + 1);
+            if ((top || left) && nw_same && !n_same && !w_same) unite_glb(par, p, p - W - 1, bad);
+            if (c + 1 < W && (top || right) && !n_same && k_ne == k) unite_glb(par, p, p - W + 1, bad);
         }
     }
 }
@@ -195,7 +196,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total)
 template <typename Pred>
 __global__ void __launch_bounds__(256) ccl_flatten_count_kernel(int *__restrict__ parent, int *__restrict__ labels,
                                                                  int *__restrict__ blockcount, Pred pred, int64_t n, int nblk,
-                                                                 bool flatten)
+                                                                 bool flatten, int *__restrict__ corrupt)
 {
     const int b = blockIdx.y;
     int *par = parent + (int64_t)b * n;
@@ -215,9 +216,12 @@ __global__ void __launch_bounds__(256) ccl_flatten_count_kernel(int *__restrict_
         int p = pv[j];
         isroot[j] = false;
         if (i >= n || p < 0) continue;
+        if (!walk_ok((int)i, p)) {  // an entry above its own index (or past the frame): not a union-find image
+            walk_corrupt(corrupt ? corrupt + b : nullptr);
+            continue;
+        }
         if (flatten) {
-            int x = p, q;
-            while ((q = par[x]) != x) x = q;
+            const int x = walk_root(par, p, corrupt ? corrupt + b : nullptr);
             if (x != p) par[i] = x;
             p = x;
         }
@@ -232,7 +236,8 @@ __global__ void __launch_bounds__(256) ccl_flatten_count_kernel(int *__restrict_
 }
 
 // one block per frame: exclusive scan of the block totals, frame total -> counts
-__global__ void __launch_bounds__(256) ccl_scan_blocks_kernel(int *__restrict__ blockcount, int *__restrict__ counts, int nblk)
+__global__ void __launch_bounds__(256) ccl_scan_blocks_kernel(int *__restrict__ blockcount, int *__restrict__ counts, int nblk,
+                                                               const int *__restrict__ corrupt)
 {
     int *bc = blockcount + (int64_t)blockIdx.x * nblk;
     int carry = 0;
@@ -244,7 +249,8 @@ __global__ void __launch_bounds__(256) ccl_scan_blocks_kernel(int *__restrict__ 
         if (i < nblk) bc[i] = carry + ex;
         carry += total;
     }
-    if (threadIdx.x == 0 && counts) counts[blockIdx.x] = carry;
+    // a frame whose union-find image broke a walk's fence (common.h, walk_ok) reports -1 components
+    if (threadIdx.x == 0 && counts) counts[blockIdx.x] = (corrupt && corrupt[blockIdx.x]) ? -1 : carry;
 }
 
 // chase: the parents are not flattened (the counting pass only looked for roots, parent[i] == i): every pixel walks to
@@ -252,7 +258,7 @@ __global__ void __launch_bounds__(256) ccl_scan_blocks_kernel(int *__restrict__ 
 // that reads and rewrites the whole union-find image
 template <typename Pred>
 __global__ void __launch_bounds__(256) ccl_relabel_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
-                                                           Pred pred, int64_t n, int nblk, bool chase)
+                                                           Pred pred, int64_t n, int nblk, bool chase, int *__restrict__ counts)
 {
     const int b = blockIdx.y;
     const int *par = parent + (int64_t)b * n;
@@ -269,16 +275,20 @@ __global__ void __launch_bounds__(256) ccl_relabel_kernel(const int *__restrict_
     }
     int out[4];
     int root_of_prev = -1, prev_p = -2;
+    int bad = 0;  // a walk left its fence (common.h, walk_ok): the frame's count becomes -1, nothing is followed
     for (int j = 0; j < 4; ++j) {
         int p = pv[j];
         int v = 0;
+        if (p >= 0 && !walk_ok((int)(i0 + j), p)) {
+            bad = 1;
+            p = -1;
+        }
         if (chase && p >= 0) {
             if (p == prev_p) {
                 p = root_of_prev;  // same entry as the pixel to the left: its walk is the answer
             } else {
                 prev_p = p;
-                int q;
-                while ((q = par[p]) != p) p = q;
+                p = walk_root(par, p, &bad);
                 root_of_prev = p;
             }
         }
@@ -294,6 +304,7 @@ __global__ void __launch_bounds__(256) ccl_relabel_kernel(const int *__restrict_
         for (int j = 0; j < 4; ++j)
             if (i0 + j < n) lab[i0 + j] = out[j];
     }
+    if (bad && counts) counts[b] = -1;
 }
 
 // The same pass for n % 4 == 0, RELABEL_Q quads per lane (a block covers RELABEL_Q * SCAN_PIX pixels, quad q of a lane
@@ -307,12 +318,9 @@ constexpr int RELABEL_Q = 4;
 
 template <typename Pred>
 __device__ __forceinline__ int relabel_decode(const int *par, int *lab, const int *blockoff, const Pred &pred, int b, int64_t n, int nblk,
-                                              int p, bool chase)
+                                              int p, bool chase, int *bad)
 {
-    if (chase) {
-        int q;
-        while ((q = par[p]) != p) p = q;
-    }
+    if (chase) p = walk_root(par, p, bad);
     if (!pred((int64_t)b * n + p)) return 0;
     int v = __hip_atomic_load(lab + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // rank code or final label
     if (v < 0) v = blockoff[b * nblk + p / SCAN_PIX] - v;
@@ -322,7 +330,7 @@ __device__ __forceinline__ int relabel_decode(const int *par, int *lab, const in
 // NCH chains in lockstep: root[q] (-1 = none) walks to its root, val[q] becomes the root's decoded label
 template <typename Pred, int NCH>
 __device__ __forceinline__ void relabel_chains(const int *par, int *lab, const int *blockoff, const Pred &pred, int b, int64_t n, int nblk,
-                                               bool chase, int (&root)[NCH], int (&val)[NCH])
+                                               bool chase, int (&root)[NCH], int (&val)[NCH], int *bad)
 {
     if (chase) {
         bool more = true;
@@ -333,6 +341,11 @@ __device__ __forceinline__ void relabel_chains(const int *par, int *lab, const i
             more = false;
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
+                // fenced (common.h, walk_ok): an entry above its index ends the chain where it stands and flags the frame
+                if (root[q] >= 0 && !walk_ok(root[q], nx[q])) {
+                    *bad = 1;
+                    nx[q] = root[q];
+                }
                 more = more || nx[q] != root[q];
                 root[q] = nx[q];
             }
@@ -354,7 +367,7 @@ __device__ __forceinline__ void relabel_chains(const int *par, int *lab, const i
 
 template <typename Pred>
 __global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
-                                                                 Pred pred, int64_t n, int nblk, bool chase)
+                                                                 Pred pred, int64_t n, int nblk, bool chase, int *__restrict__ counts)
 {
     const int b = blockIdx.y;
     const int *par = parent + (int64_t)b * n;
@@ -365,6 +378,17 @@ __global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__res
     for (int q = 0; q < RELABEL_Q; ++q) {
         const int64_t i = i0 + (int64_t)q * SCAN_PIX;
         pq[q] = i < n ? *reinterpret_cast<const int4 *>(par + i) : make_int4(-1, -1, -1, -1);
+    }
+    // the entries themselves are fenced first (common.h, walk_ok): an entry above the index it is stored at -- or past the
+    // frame -- is not a union-find entry; it becomes background and the frame's count -1
+    int bad = 0;
+#pragma unroll
+    for (int q = 0; q < RELABEL_Q; ++q) {
+        const int i = (int)(i0 + (int64_t)q * SCAN_PIX);
+        if (pq[q].x >= 0 && !walk_ok(i, pq[q].x)) { bad = 1; pq[q].x = -1; }
+        if (pq[q].y >= 0 && !walk_ok(i + 1, pq[q].y)) { bad = 1; pq[q].y = -1; }
+        if (pq[q].z >= 0 && !walk_ok(i + 2, pq[q].z)) { bad = 1; pq[q].z = -1; }
+        if (pq[q].w >= 0 && !walk_ok(i + 3, pq[q].w)) { bad = 1; pq[q].w = -1; }
     }
     // First batch: the quads' first entries.  Neighbouring lanes mostly carry the same entry: only the first lane of each
     // run of equal entries walks, the others take its answer with one cross-lane read.
@@ -393,7 +417,7 @@ __global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__res
             else if (pv[j] != lead2[q]) third = true;
         }
     }
-    relabel_chains(par, lab, blockoff, pred, b, n, nblk, chase, root, val);
+    relabel_chains(par, lab, blockoff, pred, b, n, nblk, chase, root, val, &bad);
     bool any2 = false;
 #pragma unroll
     for (int q = 0; q < RELABEL_Q; ++q) {
@@ -401,7 +425,7 @@ __global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__res
         root[q] = lead2[q];
         any2 = any2 || lead2[q] >= 0;
     }
-    if (__any(any2)) relabel_chains(par, lab, blockoff, pred, b, n, nblk, chase, root, val2);
+    if (__any(any2)) relabel_chains(par, lab, blockoff, pred, b, n, nblk, chase, root, val2, &bad);
 #pragma unroll
     for (int q = 0; q < RELABEL_Q; ++q) {
         const int64_t i = i0 + (int64_t)q * SCAN_PIX;
@@ -414,10 +438,11 @@ __global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__res
             if (pv[j] < 0) continue;
             if (pv[j] == lead[q]) out[j] = val[q];
             else if (pv[j] == lead2[q]) out[j] = val2[q];
-            else if (third) out[j] = relabel_decode(par, lab, blockoff, pred, b, n, nblk, pv[j], chase);
+            else if (third) out[j] = relabel_decode(par, lab, blockoff, pred, b, n, nblk, pv[j], chase, &bad);
         }
         *reinterpret_cast<int4 *>(lab + i) = make_int4(out[0], out[1], out[2], out[3]);
     }
+    if (bad && counts) counts[b] = -1;
 }
 
 // ---- host-side drivers ---------------------------------------------------
@@ -425,13 +450,14 @@ struct CclWs {
     int *parent;
     int *blockcount;
     int nblk;
+    int *corrupt;  // [B], cleared by ccl_roots / the callers that bring their own parents
 };
 
 static size_t ccl_ws_bytes(int B, int H, int W)
 {
     int64_t n = (int64_t)H * W;
     int nblk = (int)((n + SCAN_PIX - 1) / SCAN_PIX);
-    return align_up(sizeof(int) * (size_t)B * n) + align_up(sizeof(int) * (size_t)B * nblk);
+    return align_up(sizeof(int) * (size_t)B * n) + align_up(sizeof(int) * (size_t)B * nblk) + align_up(sizeof(int) * (size_t)B);
 }
 
 static CclWs ccl_carve(Carver &cv, int B, int H, int W)
@@ -441,12 +467,15 @@ static CclWs ccl_carve(Carver &cv, int B, int H, int W)
     ws.nblk = (int)((n + SCAN_PIX - 1) / SCAN_PIX);
     ws.parent = cv.take<int>((size_t)B * n);
     ws.blockcount = cv.take<int>((size_t)B * ws.nblk);
+    ws.corrupt = cv.take<int>((size_t)B);
     return ws;
 }
 
 template <typename KeyFn, bool CONN8>
-static int ccl_roots(KeyFn keyfn, int *parent, int B, int H, int W, hipStream_t s, bool tile_pass_done = false)
+static int ccl_roots(KeyFn keyfn, int *parent, int B, int H, int W, hipStream_t s, bool tile_pass_done = false, int *corrupt = nullptr)
 {
+    // `corrupt` ([B], may be null): cleared here, raised by a fenced walk of the border pass or of a later pass (walk_ok)
+    if (corrupt) PCSEG_CHECK_HIP(hipMemsetAsync(corrupt, 0, sizeof(int) * (size_t)B, s));
     dim3 tgrid((W + CCL_TW - 1) / CCL_TW, (H + CCL_TH - 1) / CCL_TH, B);
     if (!tile_pass_done) {
         PCSEG_LAUNCH((ccl_tile_kernel<KeyFn, CONN8>), tgrid, dim3(256), 0, s, keyfn, parent, H, W);
@@ -455,7 +484,7 @@ static int ccl_roots(KeyFn keyfn, int *parent, int B, int H, int W, hipStream_t 
     if (tgrid.x > 1 || tgrid.y > 1) {
         const int64_t border_px = (int64_t)((H - 1) / CCL_TH) * W + (int64_t)(CONN8 ? 2 : 1) * ((W - 1) / CCL_TW) * H;
         dim3 bgrid((unsigned)((border_px + 255) / 256), B);
-        PCSEG_LAUNCH((ccl_border_kernel<KeyFn, CONN8>), bgrid, dim3(256), 0, s, keyfn, parent, H, W);
+        PCSEG_LAUNCH((ccl_border_kernel<KeyFn, CONN8>), bgrid, dim3(256), 0, s, keyfn, parent, H, W, corrupt);
         PCSEG_CHECK_LAUNCH();
     }
     return PCSEG_OK;
@@ -464,23 +493,23 @@ static int ccl_roots(KeyFn keyfn, int *parent, int B, int H, int W, hipStream_t 
 // parent must hold roots that are NOT yet flattened when flatten == true
 template <typename Pred>
 static int ccl_compact(int *parent, int *blockcount, int nblk, int *labels, int *counts, Pred pred, bool flatten,
-                       int B, int H, int W, hipStream_t s)
+                       int B, int H, int W, hipStream_t s, int *corrupt = nullptr)
 {
     int64_t n = (int64_t)H * W;
     dim3 grid(nblk, B);
     // roots are exact after the border pass (parent[i] == i), so they can be counted and ranked without flattening;
     // `flatten` (the parents are not flat yet) only tells the relabel pass to walk to the roots itself
-    PCSEG_LAUNCH((ccl_flatten_count_kernel<Pred>), grid, dim3(256), 0, s, parent, labels, blockcount, pred, n, nblk, false);
+    PCSEG_LAUNCH((ccl_flatten_count_kernel<Pred>), grid, dim3(256), 0, s, parent, labels, blockcount, pred, n, nblk, false, corrupt);
     PCSEG_CHECK_LAUNCH();
-    PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, blockcount, counts, nblk);
+    PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, blockcount, counts, nblk, (const int *)corrupt);
     PCSEG_CHECK_LAUNCH();
     if ((n & 3) == 0 && (((uintptr_t)parent | (uintptr_t)labels) & 15) == 0) {
         const dim3 qgrid((unsigned)((n + SCAN_PIX * RELABEL_Q - 1) / (SCAN_PIX * RELABEL_Q)), B);
         PCSEG_LAUNCH((ccl_relabel_quads_kernel<Pred>), qgrid, dim3(256), 0, s, (const int *)parent, labels, (const int *)blockcount, pred, n,
-                     nblk, flatten);
+                     nblk, flatten, counts);
     } else {
         PCSEG_LAUNCH((ccl_relabel_kernel<Pred>), grid, dim3(256), 0, s, (const int *)parent, labels, (const int *)blockcount, pred, n, nblk,
-                     flatten);
+                     flatten, counts);
     }
     PCSEG_CHECK_LAUNCH();
     return PCSEG_OK;
@@ -496,9 +525,9 @@ static int ccl_full(KeyFn keyfn, int32_t *labels, int32_t *counts, int B, int H,
         set_error("ccl: workspace too small (%zu < %zu)", workspace_bytes, cv.off);
         return PCSEG_ERR_WORKSPACE;
     }
-    int rc = ccl_roots<KeyFn, CONN8>(keyfn, ws.parent, B, H, W, s);
+    int rc = ccl_roots<KeyFn, CONN8>(keyfn, ws.parent, B, H, W, s, false, ws.corrupt);
     if (rc) return rc;
-    return ccl_compact(ws.parent, ws.blockcount, ws.nblk, labels, counts, PredAll(), true, B, H, W, s);
+    return ccl_compact(ws.parent, ws.blockcount, ws.nblk, labels, counts, PredAll(), true, B, H, W, s, ws.corrupt);
 }
 
 int ccl_plan(void *workspace, size_t workspace_bytes, int B, int H, int W, CclPlan *plan, const char *who)
@@ -512,6 +541,7 @@ int ccl_plan(void *workspace, size_t workspace_bytes, int B, int H, int W, CclPl
     plan->parent = ws.parent;
     plan->blockcount = ws.blockcount;
     plan->nblk = ws.nblk;
+    plan->corrupt = ws.corrupt;
     return PCSEG_OK;
 }
 
@@ -519,6 +549,7 @@ int ccl_equal_u8_finish(const uint8_t *in, const CclPlan &plan, bool tile_pass_d
                         hipStream_t s)
 {
     const KeyEqU8 keyfn{in, W, (int64_t)H * W};
+    PCSEG_CHECK_HIP(hipMemsetAsync(plan.corrupt, 0, sizeof(int) * (size_t)B, s));
     dim3 tgrid((W + CCL_TW - 1) / CCL_TW, (H + CCL_TH - 1) / CCL_TH, B);
     if (!tile_pass_done) {
         PCSEG_LAUNCH((ccl_tile_kernel<KeyEqU8, true>), tgrid, dim3(256), 0, s, keyfn, plan.parent, H, W);
@@ -527,10 +558,10 @@ int ccl_equal_u8_finish(const uint8_t *in, const CclPlan &plan, bool tile_pass_d
     if (tgrid.x > 1 || tgrid.y > 1) {
         const int64_t border_px = (int64_t)((H - 1) / CCL_TH) * W + (int64_t)2 * ((W - 1) / CCL_TW) * H;
         dim3 bgrid((unsigned)((border_px + 255) / 256), B);
-        PCSEG_LAUNCH((ccl_border_kernel<KeyEqU8, true>), bgrid, dim3(256), 0, s, keyfn, plan.parent, H, W);
+        PCSEG_LAUNCH((ccl_border_kernel<KeyEqU8, true>), bgrid, dim3(256), 0, s, keyfn, plan.parent, H, W, plan.corrupt);
         PCSEG_CHECK_LAUNCH();
     }
-    return ccl_compact(plan.parent, plan.blockcount, plan.nblk, labels, counts, PredAll(), true, B, H, W, s);
+    return ccl_compact(plan.parent, plan.blockcount, plan.nblk, labels, counts, PredAll(), true, B, H, W, s, plan.corrupt);
 }
 
 // ---- roots(+1) image -> parent(-1 bg) conversion for pcseg_compact_labels
@@ -855,9 +886,8 @@ __global__ void __launch_bounds__(256) ccl_flatten_kernel(int *__restrict__ pare
     if (i >= n) return;
     int *par = parent + (int64_t)blockIdx.y * n;
     int p = par[i];
-    if (p < 0) return;
-    int x = p, q;
-    while ((q = par[x]) != x) x = q;
+    if (p < 0 || !walk_ok((int)i, p)) return;
+    const int x = walk_root(par, p);  // fenced (common.h, walk_ok)
     if (x != p) par[i] = x;
 }
 
@@ -1015,8 +1045,8 @@ __global__ void __launch_bounds__(256) locmax_propagate_kernel(int *__restrict__
         const int i = (int)(g - fbase);
         int *par = parent + fbase;
         const int p = par[i];
-        int x = p, q;
-        while ((q = par[x]) != x) x = q;
+        if (!walk_ok(i, p)) continue;   // fenced (common.h, walk_ok)
+        const int x = walk_root(par, p);
         if (x != p) par[i] = x;
         if (x != i && bad[g]) bad[fbase + x] = 1;
     }
@@ -1279,9 +1309,12 @@ int pcseg_compact_labels(const int32_t *roots, int32_t *labels, int32_t *counts,
         return PCSEG_ERR_WORKSPACE;
     }
     int64_t total = (int64_t)B * H * W;
+    // the caller's roots are walked like the library's own parents: fenced (common.h, walk_ok) -- an entry that is not "index
+    // of an earlier-or-equal pixel of the same frame, + 1" makes counts[b] = -1 instead of a wild load
+    PCSEG_CHECK_HIP(hipMemsetAsync(ws.corrupt, 0, sizeof(int) * (size_t)B, s));
     PCSEG_LAUNCH(roots_to_parent_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, roots, ws.parent, total);
     PCSEG_CHECK_LAUNCH();
-    return ccl_compact(ws.parent, ws.blockcount, ws.nblk, labels, counts, PredAll(), true, B, H, W, s);
+    return ccl_compact(ws.parent, ws.blockcount, ws.nblk, labels, counts, PredAll(), true, B, H, W, s, ws.corrupt);
 }
 
 size_t pcseg_fill_holes_workspace_bytes(int B, int H, int W)
@@ -1365,7 +1398,7 @@ int pcseg_local_maxima_i32(const int32_t *img, uint8_t *is_max, int32_t *markers
         PCSEG_LAUNCH((locmax_count_kernel<PredNotFlagged>), grid, dim3(256), 0, s, (const int *)ws.parent, markers, ws.blockcount,
                      (const unsigned long long *)cbits, pred, n, ws.nblk);
         PCSEG_CHECK_LAUNCH();
-        PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, ws.blockcount, counts, ws.nblk);
+        PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, ws.blockcount, counts, ws.nblk, (const int *)nullptr);
         PCSEG_CHECK_LAUNCH();
         PCSEG_LAUNCH((locmax_relabel_kernel<PredNotFlagged>), grid, dim3(256), 0, s, (const int *)ws.parent, markers,
                      (const int *)ws.blockcount, (const unsigned long long *)cbits, pred, n, ws.nblk);

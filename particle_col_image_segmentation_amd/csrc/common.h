@@ -193,26 +193,59 @@ __device__ __forceinline__ void unite_lds_pair(int *par, int a, int b)
 }
 
 // ---- global union-find (parents only ever decrease; stale reads cost iterations, never correctness)
-__device__ __forceinline__ int find_glb(int *par, int x)
+//
+// WALKS ARE FENCED.  In a well-formed union-find image the entry stored at index x is a smaller-or-equal index of the same
+// set and never negative (roots are minima; unions only ever lower an entry), so a walk is strictly decreasing: finite and
+// inside [0, x].  `walk_ok` is ONE unsigned compare that holds a walk to exactly that, whatever the array contains -- an
+// image that is being rewritten by another instance of the same chain (one captured graph replayed on several streams at
+// once: profiles/r03/exp_graph_r3a.log) or roots handed in by a caller (pcseg_compact_labels) then
+// ends in an error flag (`corrupt`, may be null: the walk just stops) instead of a load from a wild address or a loop
+// that never ends.
+__device__ __forceinline__ bool walk_ok(int x, int p) { return (unsigned)p <= (unsigned)x; }
+__device__ __forceinline__ void walk_corrupt(int *corrupt)
+{
+    if (corrupt) __hip_atomic_store(corrupt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// plain (read-only) walk to the root of x; x must be a valid index
+__device__ __forceinline__ int walk_root(const int *par, int x, int *corrupt = nullptr)
+{
+    int q;
+    while ((q = par[x]) != x) {
+        if (!walk_ok(x, q)) {
+            walk_corrupt(corrupt);
+            break;
+        }
+        x = q;
+    }
+    return x;
+}
+
+__device__ __forceinline__ int find_glb(int *par, int x, int *corrupt = nullptr)
 {
     // path halving: re-pointing x at its grandparent is always valid (any ancestor is) and races are benign
     int p;
     while ((p = ld_agent(par + x)) != x) {
+        if (!walk_ok(x, p)) { walk_corrupt(corrupt); return x; }
         int g = ld_agent(par + p);
+        if (!walk_ok(p, g)) { walk_corrupt(corrupt); return p; }
         if (g != p) __hip_atomic_store(par + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = g;
     }
     return x;
 }
 // the two walks to the roots advance in LOCKSTEP (path halving on both, as in find_glb): a step of the pair is two
-// independent loads in flight instead of one, and the border passes are nothing but these dependent walks
-__device__ __forceinline__ void find2_glb(int *par, int &a, int &b)
+// independent loads in flight instead of one, and the border passes are nothing but these dependent walks.
+// Returns false (and raises `corrupt`) when an entry breaks the fence: the caller must not link anything then.
+__device__ __forceinline__ bool find2_glb(int *par, int &a, int &b, int *corrupt = nullptr)
 {
     for (;;) {
-        if (a == b) return;
+        if (a == b) return true;
         const int pa = ld_agent(par + a), pb = ld_agent(par + b);
-        if (pa == a && pb == b) return;
+        if (pa == a && pb == b) return true;
+        if (!walk_ok(a, pa) || !walk_ok(b, pb)) break;
         const int ga = ld_agent(par + pa), gb = ld_agent(par + pb);
+        if (!walk_ok(pa, ga) || !walk_ok(pb, gb)) break;
         if (pa != a) {
             if (ga != pa) __hip_atomic_store(par + a, ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a = ga;
@@ -222,15 +255,18 @@ __device__ __forceinline__ void find2_glb(int *par, int &a, int &b)
             b = gb;
         }
     }
+    walk_corrupt(corrupt);
+    return false;
 }
-__device__ __forceinline__ void unite_glb(int *par, int a, int b)
+__device__ __forceinline__ void unite_glb(int *par, int a, int b, int *corrupt = nullptr)
 {
     for (;;) {
-        find2_glb(par, a, b);
+        if (!find2_glb(par, a, b, corrupt)) return;
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }
         int old = atomicMin(par + a, b);
         if (old == a) return;
+        if (!walk_ok(a, old)) { walk_corrupt(corrupt); return; }
         a = old;
     }
 }
@@ -242,6 +278,7 @@ struct CclPlan {
     int *parent;
     int *blockcount;
     int nblk;
+    int *corrupt;  // [B] raised by a fenced walk (see walk_ok): the frame's count comes out as -1
 };
 int ccl_plan(void *workspace, size_t workspace_bytes, int B, int H, int W, CclPlan *plan, const char *who);
 int ccl_equal_u8_finish(const uint8_t *in, const CclPlan &plan, bool tile_pass_done, int *labels, int *counts, int B, int H, int W,

@@ -821,16 +821,12 @@ __global__ void __launch_bounds__(256) merge_keys_kernel(const int *__restrict__
                     if ((word >> j) & 1u) {
                         const unsigned below = ~word & ((1u << j) - 1u);
                         const int start = below ? 32 - __clz(below) : 0;
-                        key_k = (int)((y - j + start) * W + x);
-                        int q;
-                        while ((q = dlab[key_k]) != key_k) key_k = q;
-                        key_k += 1;
+                        key_k = walk_root(dlab, (int)((y - j + start) * W + x)) + 1;  // fenced (common.h, walk_ok)
                     }
                 } else {
                     key_k = dlab[y * W + x];
                     if (keys_are_roots) {  // parent image of a union-find (-1 = background): walk to the root
-                        int q;
-                        while (key_k >= 0 && (q = dlab[key_k]) != key_k) key_k = q;
+                        if (key_k >= 0) key_k = (unsigned)key_k < (unsigned)(H * W) ? walk_root(dlab, key_k) : -1;  // fenced
                         key_k += 1;
                     }
                 }
@@ -971,10 +967,7 @@ __global__ void __launch_bounds__(MG_THREADS) merge_fused_kernel(const unsigned 
                     if ((word >> j) & 1u) {
                         const unsigned below = ~word & ((1u << j) - 1u);
                         const int start = below ? 32 - __clz(below) : 0;
-                        key_k = (int)((y - j + start) * W + x);
-                        int q;
-                        while ((q = par[key_k]) != key_k) key_k = q;
-                        key_k += 1;
+                        key_k = walk_root(par, (int)((y - j + start) * W + x)) + 1;  // fenced (common.h, walk_ok)
                     }
                 }
             }

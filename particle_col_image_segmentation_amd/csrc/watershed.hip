@@ -715,27 +715,28 @@ __device__ __forceinline__ void vunite_lds(int *par, int a, int b)
         a = old;
     }
 }
-__device__ __forceinline__ int vfind_glb(int *par, int v)
-{
-    int p;
-    while ((p = ld_agent(par + (v & (UF_NS - 1)))) != v) {
-        int g = ld_agent(par + (p & (UF_NS - 1)));
-        if (g != p) __hip_atomic_store(par + (v & (UF_NS - 1)), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = g;
-    }
-    return v;
-}
+// The walks over the frame-wide parent image are FENCED like the plain ones (common.h, walk_ok): an entry stored for the node
+// with virtual index x is a virtual index <= x (roots are minima of the virtual order, unions only lower entries) whose
+// pixel lies inside the frame.  Anything else -- the image being rewritten by a second instance of the same captured chain
+// (profiles/r03/exp_graph_r3a.log), a stale workspace -- stops the walk and raises the frame's tie flag (the exact flood
+// then recomputes the frame in mode 0, mode 2 reports it) instead of loading from a wild address or walking for ever.
+__device__ __forceinline__ bool vwalk_ok(int x, int p, int n) { return (unsigned)p <= (unsigned)x && (p & (UF_NS - 1)) < n; }
+
 // p, q: pixel indices; the walk starts from their parents, which are virtual indices of nodes in the same sets
-__device__ __forceinline__ void vunite_glb(int *par, int p, int q)
+__device__ __forceinline__ void vunite_glb(int *par, int p, int q, int n, int *corrupt)
 {
     int a = ld_agent(par + p), b = ld_agent(par + q);
-    for (;;) {
+    // (the pixels' own entries: any virtual index of the frame -- a seed elsewhere may precede both)
+    bool ok = a >= 0 && b >= 0 && (a & (UF_NS - 1)) < n && (b & (UF_NS - 1)) < n;
+    while (ok) {
         // both walks in lockstep (see find2_glb)
         for (;;) {
             if (a == b) return;
             const int pa = ld_agent(par + (a & (UF_NS - 1))), pb = ld_agent(par + (b & (UF_NS - 1)));
             if (pa == a && pb == b) break;
+            if (!vwalk_ok(a, pa, n) || !vwalk_ok(b, pb, n)) { ok = false; break; }
             const int ga = ld_agent(par + (pa & (UF_NS - 1))), gb = ld_agent(par + (pb & (UF_NS - 1)));
+            if (!vwalk_ok(pa, ga, n) || !vwalk_ok(pb, gb, n)) { ok = false; break; }
             if (pa != a) {
                 if (ga != pa) __hip_atomic_store(par + (a & (UF_NS - 1)), ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 a = ga;
@@ -745,12 +746,28 @@ __device__ __forceinline__ void vunite_glb(int *par, int p, int q)
                 b = gb;
             }
         }
+        if (!ok) break;
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }
         int old = atomicMin(par + (a & (UF_NS - 1)), b);
         if (old == a) return;
+        if (!vwalk_ok(a, old, n)) break;
         a = old;
     }
+    walk_corrupt(corrupt);
+}
+// read-only walk to the root of virtual index x (x's pixel must lie inside the frame)
+__device__ __forceinline__ int vwalk_root(const int *par, int x, int n, bool &bad)
+{
+    int q;
+    while ((q = par[x & (UF_NS - 1)]) != x) {
+        if (!vwalk_ok(x, q, n)) {
+            bad = true;
+            break;
+        }
+        x = q;
+    }
+    return x;
 }
 
 template <typename KeyT>
@@ -926,7 +943,8 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__
 
 // cross-tile links from the neighbour masks the tile pass left behind
 __global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict__ frame_list, const uint8_t *__restrict__ minmask, const uint8_t *__restrict__ active,
-                                                            int *__restrict__ parent, int H, int W, int tilesX, int tilesY)
+                                                            int *__restrict__ parent, int H, int W, int tilesX, int tilesY,
+                                                            int *__restrict__ exact_flags)
 {
     // dense enumeration of the border pixels: rows that start a tile row (lanes along the row), then the first column
     // of every tile column for the remaining rows (lanes along the column)
@@ -963,14 +981,14 @@ __global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict
         if ((mp & 1) || (mu & 8)) {
             bool implied = false;
             if (!left && c > 0) implied = ((mp & 2) || (ml & 4)) && ((mu & 2) || (mul & 4)) && ((ml & 1) || (mul & 8));
-            if (!implied) vunite_glb(par, p, p - W);
+            if (!implied) vunite_glb(par, p, p - W, H * W, exact_flags + b);
         }
     }
     if (left && ws_active(active, b, r, c - 1, tilesX, tilesY)) {
         if ((mp & 2) || (ml & 4)) {
             bool implied = false;
             if (!top && r > 0) implied = ((mp & 1) || (mu & 8)) && ((ml & 1) || (mul & 8)) && ((mu & 2) || (mul & 4));
-            if (!implied) vunite_glb(par, p, p - 1);
+            if (!implied) vunite_glb(par, p, p - 1, H * W, exact_flags + b);
         }
     }
     });
@@ -992,7 +1010,8 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
                                                            const uint8_t *__restrict__ active, uint8_t *__restrict__ bad,
                                                            const int *__restrict__ markers, const uint8_t *__restrict__ mask,
                                                            int *__restrict__ tie_flags, uint8_t *__restrict__ mark_active, int64_t n,
-                                                           int W, int tilesX, int tilesY, uint8_t *__restrict__ in_bad = nullptr)
+                                                           int W, int tilesX, int tilesY, int *__restrict__ exact_flags,
+                                                           uint8_t *__restrict__ in_bad = nullptr)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     ws_for_frames(frame_list, blockIdx.y, gridDim.y, [&](const int b) {
@@ -1003,8 +1022,12 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
     int x = parent[g];
     if (x < 0) return;
     const int *par = parent + fbase;
-    int q;
-    while ((q = par[x & (UF_NS - 1)]) != x) x = q;
+    bool broken = (x & (UF_NS - 1)) >= (int)n;
+    if (!broken) x = vwalk_root(par, x, (int)n, broken);
+    if (broken) {  // a walk left its fence (vwalk_ok): the frame is recomputed by the exact flood / reported
+        exact_flags[b] = 1;
+        return;
+    }
     if (x >= UF_NS) return;  // no labelled pixel in the component
     const int64_t groot = fbase + x;
     if (MODE == UF_REPAIR) {
@@ -1045,8 +1068,14 @@ constexpr int LABEL4_Q = 4;
 
 // NCH chains in lockstep: root[q] (-1 = none) walks to its root, lab[q] becomes the root's label (0: no seed)
 template <int NCH>
-__device__ __forceinline__ void label4_chains(const int *par, const int *F, int64_t fbase, int (&root)[NCH], int (&lab)[NCH])
+__device__ __forceinline__ void label4_chains(const int *par, const int *F, int64_t fbase, int n, int (&root)[NCH], int (&lab)[NCH], bool &bad)
 {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q)
+        if (root[q] >= 0 && (root[q] & (UF_NS - 1)) >= n) {  // the pixel's own entry: any virtual index of the frame
+            bad = true;
+            root[q] = -1;
+        }
     bool more = true;
     while (more) {
         int nx[NCH];
@@ -1055,6 +1084,10 @@ __device__ __forceinline__ void label4_chains(const int *par, const int *F, int6
         more = false;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
+            if (root[q] >= 0 && !vwalk_ok(root[q], nx[q], n)) {  // fenced: the chain ends unlabelled, the frame is flagged
+                bad = true;
+                nx[q] = root[q] = -1;
+            }
             more = more || nx[q] != root[q];
             root[q] = nx[q];
         }
@@ -1066,7 +1099,7 @@ __device__ __forceinline__ void label4_chains(const int *par, const int *F, int6
 
 __global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ minmask,
                                                             int *F, uint8_t *__restrict__ bad, int *__restrict__ tie_flags,
-                                                            int64_t n)
+                                                            int64_t n, int *__restrict__ exact_flags)
 {
     const int64_t i0 = (int64_t)blockIdx.x * (1024 * LABEL4_Q) + threadIdx.x * 4;
     const int b = blockIdx.y;
@@ -1115,7 +1148,8 @@ __global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict
             if (pv[j] >= 0 && pv[j] != lead[q] && lead2[q] < 0) lead2[q] = pv[j];
         rt[LABEL4_Q + q] = lead2[q];
     }
-    label4_chains(par, F, fbase, rt, lb);
+    bool broken = false;
+    label4_chains(par, F, fbase, (int)n, rt, lb, broken);
     int root[LABEL4_Q], lab[LABEL4_Q], root2[LABEL4_Q], lab2[LABEL4_Q];
 #pragma unroll
     for (int q = 0; q < LABEL4_Q; ++q) {
@@ -1142,12 +1176,16 @@ __global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict
             if (x == lead[q]) { x_root = root[q]; x_lab = lab[q]; }
             else if (x == lead2[q]) { x_root = root2[q]; x_lab = lab2[q]; }
             else {  // (third: a quad with three different entries)
-                int t;
-                while ((t = par[x & (UF_NS - 1)]) != x) x = t;
+                bool b3 = (x & (UF_NS - 1)) >= (int)n;
+                if (!b3) x = vwalk_root(par, x, (int)n, b3);
+                if (b3) {
+                    broken = true;
+                    continue;
+                }
                 x_root = x;
                 x_lab = x < UF_NS ? F[fbase + x] : 0;
             }
-            if (x_root >= UF_NS) continue;  // no labelled pixel in the component
+            if (x_root < 0 || x_root >= UF_NS) continue;  // no labelled pixel in the component (or a chain that broke its fence)
             if (!seed) {
                 fv[j] = x_lab;
                 wrote = true;
@@ -1158,6 +1196,7 @@ __global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict
         }
         if (wrote) *reinterpret_cast<int4 *>(F + fbase + i) = make_int4(fv[0], fv[1], fv[2], fv[3]);
     }
+    if (broken) exact_flags[b] = 1;  // a walk left its fence (vwalk_ok): recomputed by the exact flood / reported
 }
 
 // (3) proof check: every neighbour whose key equals the minimum neighbour key carries the pixel's label
@@ -1915,24 +1954,24 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             PCSEG_CHECK_LAUNCH();
             if (border_px > 0) {
                 PCSEG_LAUNCH(ws_uf_border_kernel, bgrid, dim3(256), 0, s, flist, (const uint8_t *)uf_mask, act, uf_parent, H, W,
-                             tilesX, tilesY);
+                             tilesX, tilesY, flags2);
                 PCSEG_CHECK_LAUNCH();
             }
             if (first_level && act == nullptr && flist == nullptr && (W & 3) == 0 && (((uintptr_t)out | (uintptr_t)uf_parent) & 15) == 0 &&
                 ((uintptr_t)uf_mask & 3) == 0) {
                 PCSEG_LAUNCH(ws_uf_label4_kernel, dim3((unsigned)((npx + 1024 * LABEL4_Q - 1) / (1024 * LABEL4_Q)), B), dim3(256), 0, s,
-                             (const int *)uf_parent, (const uint8_t *)uf_mask, out, uf_bad1, out_flags, npx);
+                             (const int *)uf_parent, (const uint8_t *)uf_mask, out, uf_bad1, out_flags, npx, flags2);
                 PCSEG_CHECK_LAUNCH();
             } else if (first_level) {
                 PCSEG_LAUNCH(ws_uf_label_kernel<UF_OPTIMISTIC>, lgrid, dim3(256), 0, s, flist, (const int *)uf_parent, out, act,
-                             uf_bad1, markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY);
+                             uf_bad1, markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY, flags2);
                 PCSEG_CHECK_LAUNCH();
             } else {
                 PCSEG_LAUNCH(ws_uf_label_kernel<UF_DETECT>, lgrid, dim3(256), 0, s, flist, (const int *)uf_parent, out, act, uf_bad2,
-                             markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY);
+                             markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY, flags2);
                 PCSEG_CHECK_LAUNCH();
                 PCSEG_LAUNCH(ws_uf_label_kernel<UF_ASSIGN>, lgrid, dim3(256), 0, s, flist, (const int *)uf_parent, out, act, uf_bad2,
-                             markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY);
+                             markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY, flags2);
                 PCSEG_CHECK_LAUNCH();
             }
             return PCSEG_OK;
@@ -1960,7 +1999,7 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             // it; the verification build checks keys over whole frames and keeps every lake)
             uint8_t *in_bad = verify ? nullptr : uf_bad2;
             PCSEG_LAUNCH(ws_uf_label_kernel<UF_REPAIR>, lgrid, dim3(256), 0, s, (const int *)frame_list, (const int *)uf_parent, out,
-                         (const uint8_t *)nullptr, uf_bad1, markers, mask, flags, active, npx, W, tilesX, tilesY, in_bad);
+                         (const uint8_t *)nullptr, uf_bad1, markers, mask, flags, active, npx, W, tilesX, tilesY, flags2, in_bad);
             PCSEG_CHECK_LAUNCH();
             if (verify) {
                 // whole flagged frames, so that the explicit per-pixel check of the second level sees valid keys everywhere

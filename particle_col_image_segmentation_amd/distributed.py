@@ -17,44 +17,84 @@ def shard_frames(n_frames, rank, world_size):
     return list(range(rank, n_frames, world_size))
 
 
-def all_gather_table(table, group=None, sort_cols=(0, 1), presorted=False):
+def _dist_on(group=None):
+    return dist.is_available() and dist.is_initialized()
+
+
+def _lexsort_rows(table, sort_cols):
+    """Rows ordered by the key columns, first key most significant, as a chain of STABLE sorts (exact for any float64
+    key values; rows with equal keys keep their order -- the `distances` rows of a frame are slot 0 first, then slot 1,
+    .m:264-268, and must stay that way whatever the number of ranks)."""
+    order = torch.arange(table.shape[0], device=table.device)
+    for c in reversed(tuple(sort_cols)):
+        order = order[torch.sort(table[order, c], stable=True)[1]]
+    return table[order]
+
+
+GATHER_CHUNK_BYTES = 64 << 20  # per table and rank: BASELINE config 5's 460 MB per rank never needs world x max_rows at once
+
+
+def _gather_rows(tables, group=None, chunk_bytes=None):
+    """all-gather a list of (rows_r, cols) tables of one dtype/device: ONE exchange of all the row counts, then every
+    table in chunks of at most ``chunk_bytes`` per rank through ``all_gather_into_tensor`` on one preallocated buffer,
+    each rank's valid rows copied straight to their place (rank-major) in the output."""
+    world = dist.get_world_size(group)
+    dev = tables[0].device
+    chunk_bytes = int(chunk_bytes or GATHER_CHUNK_BYTES)
+    mine = torch.tensor([int(t.shape[0]) for t in tables], dtype=torch.int64, device=dev)
+    counts = torch.zeros((world, len(tables)), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts.view(-1), mine, group=group)
+    counts = counts.cpu().tolist()  # the one host sync of the gather
+    out = []
+    for k, t in enumerate(tables):
+        cols = int(t.shape[1])
+        per_rank = [int(c[k]) for c in counts]
+        starts = [0]
+        for c in per_rank:
+            starts.append(starts[-1] + c)
+        res = torch.empty((starts[-1], cols), dtype=t.dtype, device=dev)
+        most = max(per_rank)
+        if most and cols:
+            chunk_rows = max(1, min(most, chunk_bytes // (cols * t.element_size())))
+            send = torch.zeros((chunk_rows, cols), dtype=t.dtype, device=dev)
+            recv = torch.empty((world, chunk_rows, cols), dtype=t.dtype, device=dev)
+            for lo in range(0, most, chunk_rows):
+                n = max(0, min(int(t.shape[0]) - lo, chunk_rows))
+                if n:
+                    send[:n] = t[lo:lo + n]
+                dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+                for r in range(world):
+                    m = max(0, min(per_rank[r] - lo, chunk_rows))
+                    if m:
+                        res[starts[r] + lo:starts[r] + lo + m] = recv[r, :m]
+        out.append(res)
+    return out
+
+
+def all_gather_table(table, group=None, sort_cols=(0, 1), presorted=False, chunk_bytes=None):
     """Gather (rows_r, cols) float64 tables from every rank into one table, sorted by the key columns
     (frame, label) so that the result does not depend on the number of ranks."""
-    if not dist.is_available() or not dist.is_initialized():
-        out = table
-    else:
-        world = dist.get_world_size(group)
-        dev = table.device
-        n = torch.tensor([table.shape[0]], dtype=torch.int64, device=dev)
-        counts = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(counts, n, group=group)
-        counts = [int(c.item()) for c in counts]
-        cols = table.shape[1]
-        pad = torch.zeros((max(max(counts), 1), cols), dtype=table.dtype, device=dev)
-        pad[: table.shape[0]] = table
-        parts = [torch.zeros_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad, group=group)
-        out = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
-    single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
+    single = not _dist_on() or dist.get_world_size(group) == 1
+    out = table if not _dist_on() else _gather_rows([table], group, chunk_bytes)[0]
     if presorted and single:
         return out  # one rank, rows already in (frame, label) order: nothing to merge
     if out.shape[0] and sort_cols:
-        key = out[:, sort_cols[0]].to(torch.float64)
-        for c in sort_cols[1:]:
-            key = key * (float(out[:, c].max().item()) + 1.0) + out[:, c].to(torch.float64)
-        out = out[torch.argsort(key)]
+        out = _lexsort_rows(out, sort_cols)
     return out
 
 
 TABLE_KEYS = ("cells", "rois", "frames", "groups", "distances")
-_SORT_COLS = {"frames": (0,), "frames_rec": (0,), "groups": (0, 1, 2)}
+# key columns per table.  `distances`: frame only -- a frame lives on one rank and the sort is stable, so the rows of a
+# frame keep the order their rank made them in (type slot 0 first, then slot 1), with any number of ranks
+_SORT_COLS = {"frames": (0,), "frames_rec": (0,), "groups": (0, 1, 2), "distances": (0,)}
 
 
-def gather_tables(tables, device=None, group=None, presorted=False):
+def gather_tables(tables, device=None, group=None, presorted=False, chunk_bytes=None):
     """all-gather every 2-D table of a dict (numpy arrays or tensors in, same kind out), each sorted by its key columns.
     Every rank must pass the same set of tables with the same column counts -- also a rank without a single row
-    (``(0, ncols)`` arrays)."""
+    (``(0, ncols)`` arrays).  One exchange of row counts for all tables, then chunked gathers (``_gather_rows``)."""
     out = dict(tables)
+    names, tens, was_np = [], [], []
     for name, value in tables.items():
         is_np = isinstance(value, np.ndarray)
         if not (is_np or isinstance(value, torch.Tensor)) or value.ndim != 2:
@@ -62,7 +102,20 @@ def gather_tables(tables, device=None, group=None, presorted=False):
         t = torch.from_numpy(np.ascontiguousarray(value, dtype=np.float64)) if is_np else value
         if device is not None:
             t = t.to(device)
-        g = all_gather_table(t, group, _SORT_COLS.get(name, (0, 1)), presorted and name != "distances")
+        names.append(name)
+        tens.append(t.contiguous())
+        was_np.append(is_np)
+    if not names:
+        return out
+    single = not _dist_on() or dist.get_world_size(group) == 1
+    if _dist_on():
+        same = all(t.dtype == tens[0].dtype and t.device == tens[0].device for t in tens)
+        gathered = _gather_rows(tens, group, chunk_bytes) if same else [_gather_rows([t], group, chunk_bytes)[0] for t in tens]
+    else:
+        gathered = tens
+    for name, g, is_np in zip(names, gathered, was_np):
+        if not (presorted and single) and g.shape[0]:
+            g = _lexsort_rows(g, _SORT_COLS.get(name, (0, 1)))
         out[name] = g.cpu().numpy() if is_np else g
     return out
 
@@ -116,7 +169,8 @@ class _HostRows:
         return {k: self.buf[k][:self.rows[k]].numpy() for k in self.buf}
 
 
-def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, planes=None, check=True, **table_kwargs):
+def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, planes=None, check=True, force_gather=False,
+                chunk_bytes=None, **table_kwargs):
     """BASELINE configs 3 / 5: frames ``rank, rank + world, ...`` of a dataset go through ``pipe`` in batches of
     ``batch`` and the tables of all ranks are gathered once at the end.  ``make_batch(frame_ids)`` returns the
     ``(len(frame_ids), planes, H, W)`` float32 CUDA stack of those frames (e.g. ``synth.gen_batch_torch`` per seed, or
@@ -129,7 +183,17 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
     the host epilogue (``pipe.host_tables``) then runs on the gathered rows.  A rank that owns no frame
     (``n_frames < world``) contributes ``pipe.empty_device_tables``, so that every rank enters the same collectives with
     the same column counts.  The plane count comes from the data (the first batch a rank makes; ranks agree on it with one
-    all-reduce), ``planes`` only overrides it.  ``table_kwargs`` (ratios, distances, raster) go to ``host_tables``."""
+    all-reduce), ``planes`` only overrides it.  ``table_kwargs`` (ratios, distances, raster) go to ``host_tables``.
+
+    ``force_gather``: one rank normally streams its rows to pinned host memory batch by batch (``_HostRows``: there is
+    nothing to gather); with this switch it takes the route every rank of a larger world takes -- device tables
+    concatenated, ``gather_tables`` through the process group (RCCL for CUDA tensors), one download -- so that the N > 1
+    path can be exercised on one GPU.  ``chunk_bytes``: per-rank chunk of the gather (default 64 MB).
+
+    Graph-mode pipelines (``FramePipeline(graph=True)``): a lane's replay reads the input buffer it was captured on, so
+    ``make_batch`` may only refill a buffer whose previous batch has finished.  The oldest pending batch's tables are
+    therefore taken (which waits for that batch) BEFORE ``make_batch`` is called for the batch that reuses its lane:
+    with ``lanes`` in flight a caller needs ``lanes`` rotating input buffers, not ``lanes + 1``."""
     rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     mine = shard_frames(n_frames, rank, world)
@@ -140,7 +204,7 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
 
     def take(part):
         nonlocal host_rows
-        if world == 1 and all(isinstance(v, torch.Tensor) and v.is_cuda and v.ndim == 2 for v in part.values()):
+        if world == 1 and not force_gather and all(isinstance(v, torch.Tensor) and v.is_cuda and v.ndim == 2 for v in part.values()):
             if host_rows is None:
                 host_rows = _HostRows(next(iter(part.values())).device, n_batches)
             host_rows.append(part)
@@ -152,15 +216,15 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
     seen_planes = 0
     for i in range(0, len(mine), batch):            # waits for its batch) only once that many newer batches are queued
         ids = mine[i:i + batch]
-        frames = make_batch(ids)
-        if not seen_planes and hasattr(frames, "shape") and len(frames.shape) == 4:
-            seen_planes = int(frames.shape[1])
-        # a graph-mode pipeline keeps `lanes` results alive (a lane's next replay overwrites its previous result): the
-        # oldest batch's tables are taken BEFORE the batch that reuses its lane is handed over -- the wait for it runs
-        # under the other lanes' kernels
+        # a graph-mode pipeline keeps `lanes` results alive (a lane's next replay overwrites its previous result, and reads
+        # the input buffer it was captured on): the oldest batch's tables are taken BEFORE the feeder refills that buffer
+        # and before the batch that reuses its lane is handed over -- the wait for it runs under the other lanes' kernels
         while getattr(pipe, "graph", False) and len(pending) >= depth:
             res, rid = pending.popleft()
             take(pipe.tables_device(res, frame_ids=rid, check=check, **ratio_kw))
+        frames = make_batch(ids)
+        if not seen_planes and hasattr(frames, "shape") and len(frames.shape) == 4:
+            seen_planes = int(frames.shape[1])
         pending.append((pipe.run(frames), ids))
         # ... and the tables of every batch that has finished meanwhile are taken right away (in order): what is left
         # to drain after the last batch is then only what is still running
@@ -181,5 +245,6 @@ def run_sharded(n_frames, make_batch, pipe, batch=64, group=None, device=None, p
         merged = pipe.empty_device_tables(planes, device=device, **({"ratios": ratio_kw["ratios"]} if "ratios" in ratio_kw else {}))
     # (a rank's own rows come out of the batches in frame order, labels ascending: with one rank that IS the gathered
     # order and the sort is skipped)
-    gathered = gather_tables(merged, device=device, group=group, presorted=world == 1 and mine == sorted(mine))
+    gathered = gather_tables(merged, device=device, group=group, presorted=world == 1 and mine == sorted(mine),
+                             chunk_bytes=chunk_bytes)
     return pipe.host_tables(gathered, planes, **table_kwargs)

@@ -89,51 +89,52 @@ class BatchResult(dict):
         return self
 
     def __getitem__(self, key):
+        self._settle()
+        return dict.__getitem__(self, key)
+
+    def _settle(self):
+        """every accessor: wait for the batch once, and refuse a graph-mode result whose lane has replayed since"""
         if self._pending:
             self.synchronize()
         elif self._slot is not None:
             self._check_alive()
-        return dict.__getitem__(self, key)
 
     def get(self, key, default=None):
-        if self._pending:
-            self.synchronize()
+        self._settle()
         return dict.get(self, key, default)
 
     def items(self):
-        if self._pending:
-            self.synchronize()
+        self._settle()
         return dict.items(self)
 
     def values(self):
-        if self._pending:
-            self.synchronize()
+        self._settle()
         return dict.values(self)
 
     def keys(self):
-        if self._pending:
-            self.synchronize()
+        self._settle()
         return dict.keys(self)
 
     def __iter__(self):
-        if self._pending:
-            self.synchronize()
+        self._settle()
         return dict.__iter__(self)
 
     def __contains__(self, key):
-        if self._pending:
-            self.synchronize()
+        self._settle()
         return dict.__contains__(self, key)
 
     def __len__(self):
-        if self._pending:
-            self.synchronize()
+        self._settle()
         return dict.__len__(self)
 
     def check(self):
         """Raise for the conditions the reference raises for / the tables cannot hold."""
         if int(self["overflow"].sum().item()) or int(self["ws_overflow"].sum().item()):
             raise RuntimeError("region table capacity exceeded: raise FramePipeline(cap=...)")
+        if int((self["counts"] < 0).sum().item()):
+            # a label pass found a union-find entry outside its fence (csrc/common.h, walk_ok) and reported -1 components:
+            # the workspace was overwritten while the chain ran (e.g. one captured graph replayed on two streams at once)
+            raise RuntimeError("corrupt union-find image in the class-map labelling (counts < 0)")
         if int(self["nan_flag"].sum().item()):
             # tiff_analysis.py:776-781: clusters of a type without any single cell -> int(NaN)
             raise ValueError("cannot convert float NaN to integer")
@@ -287,6 +288,12 @@ class FramePipeline:
             slot.release = None
         done = torch.cuda.Event()
         with torch.cuda.stream(slot.stream):
+            # ONE instance of a captured chain at a time: a slot owns one workspace (union-find parents, overflow tables,
+            # dirty-tile lists) and one set of static outputs, so two replays of it must never overlap.  Replaying on
+            # slot.stream -- and nowhere else -- serialises them; profiles/r03/exp_graph_r3a.log is what the other way
+            # round looks like (one graph replayed on 4 streams at once: a memory-access fault).
+            if torch.cuda.current_stream(dev) != slot.stream:
+                raise RuntimeError("a graph slot may only be replayed on its own stream")
             slot.graph.replay()
             done.record(slot.stream)
         slot.gen += 1
@@ -299,7 +306,9 @@ class FramePipeline:
         inside the library (function attributes, the tile counter's allocation) must not fall into the capture."""
         dev = stack.device
         while len(self._graphs) >= self.max_graphs:
-            self._graphs.pop(next(iter(self._graphs)))  # oldest first; its memory pool goes with it
+            old = self._graphs.pop(next(iter(self._graphs)))  # oldest first; its memory pool goes with it ...
+            old.stream.synchronize()  # ... so no replay of it may still be running (a caller may have dropped its result unread)
+            old.gen += 1              # results that still alias its static tensors refuse to be read from now on
         _, lane_streams = _lanes_for(dev, self.lanes)
         streams = lane_streams[lane]
         slot = _GraphSlot(torch.cuda.Stream(device=dev))
@@ -400,7 +409,7 @@ class FramePipeline:
             return
         B, C, H, W = stack.shape
         tb = self.tables_
-        if W % 4:
+        if W % 4 or res["denoised"].data_ptr() % 4:  # the batched bit pass reads the class map four bytes at a time
             for s in slots:
                 self._merge_stage(stack, res, s)
             return
@@ -413,10 +422,13 @@ class FramePipeline:
         keep = [k for k, m in enumerate(masks) if m]
         if not keep:
             return
-        dbits, run_par = ops.dilated_runs_multi(res["denoised"], [masks[k] for k in keep], ta.CELL_CLUSTER_DISTANCE_THRESHOLD // 2)
-        gof, ng, gst = ops.merge_groups_fused_multi(dbits, run_par, res["stats"], res["region_list"], res["n_list"], [slots[k] for k in keep])
-        for m, k in enumerate(keep):
-            res["groups"][slots[k]] = {"group_of": gof[m], "n_groups": ng[m], "group_stats": gst[m]}
+        # the batched kernels take up to four masks a call (MaskSet / MergeSlots are four wide): a four-type table has five
+        for lo in range(0, len(keep), 4):
+            part = keep[lo:lo + 4]
+            dbits, run_par = ops.dilated_runs_multi(res["denoised"], [masks[k] for k in part], ta.CELL_CLUSTER_DISTANCE_THRESHOLD // 2)
+            gof, ng, gst = ops.merge_groups_fused_multi(dbits, run_par, res["stats"], res["region_list"], res["n_list"], [slots[k] for k in part])
+            for m, k in enumerate(part):
+                res["groups"][slots[k]] = {"group_of": gof[m], "n_groups": ng[m], "group_stats": gst[m]}
 
     def _merge_stage(self, stack, res, s):
         """proximity merge of one cell type (s < 4) or of all types together (s = 4) (A5, A6)"""
@@ -472,7 +484,10 @@ class FramePipeline:
         for v in self.tables_.cell_values:
             cell_bits |= 1 << int(v)
         B, C, H, W = stack.shape
-        if W % 4 == 0:
+        # the fused pass reads labels and planes as 16-byte quads: a contiguous view at an odd storage offset (legal for run())
+        # takes the per-image kernels below like a ragged width does
+        aligned = all(t.data_ptr() % 16 == 0 for t in (res["labels"], res["ws_labels"], stack)) and res["denoised"].data_ptr() % 4 == 0
+        if W % 4 == 0 and aligned:
             ops.region_sums2(res["labels"], res["denoised"], cell_bits, res["cc_sums"], res["ws_labels"], res["ws_sums"], stack)
             return
         # ragged widths: the per-image kernels (their plane pass adds nothing to the already counted integer columns'

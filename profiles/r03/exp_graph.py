@@ -136,14 +136,23 @@ def main():
                     g.replay()
             print("graph5 1 stream sub=%2d : %.3f ms/step" % (sb, timeit(step, 10, 3)), flush=True)
             for k in (2, 4):
+                # ONE GRAPH PER (stream, view).  The round-3 version of this leg replayed the SAME captured graph on k streams
+                # in turn (with sb = 64 there is one graph): k instances of one chain then ran at once on one private
+                # workspace -- union-find parents, overflow tables, dirty-tile lists -- and the run ended in "Memory access
+                # fault by GPU" (exp_graph_r3a.log, right after "graph5 2 streams sub=64": a parent entry read while another
+                # instance rewrote it walked out of its frame).  A captured chain owns its workspace: it may be replayed
+                # again only after its previous replay, i.e. on ONE stream; concurrency needs a graph per stream.
                 streams = [torch.cuda.Stream() for _ in range(k)]
+                per_stream = [graphs] + [[capture_lane(stack[i:i + sb]) for i in range(0, B, sb)] for _ in range(k - 1)]
                 cnt = [0]
                 def stepk():
-                    for g, _ in graphs:
-                        with torch.cuda.stream(streams[cnt[0] % k]):
-                            g.replay()
+                    for idx in range(len(graphs)):
+                        j = cnt[0] % k
+                        with torch.cuda.stream(streams[j]):
+                            per_stream[j][idx][0].replay()
                         cnt[0] += 1
                 print("graph5 %d streams sub=%2d : %.3f ms/step" % (k, sb, timeit(stepk, 12, 4)), flush=True)
+                del per_stream
             ref = solo.run(stack[:sb])
             torch.cuda.synchronize()
             graphs[0][0].replay()

@@ -159,3 +159,46 @@ def test_exact_flood_with_more_frames_than_cus():
                                  torch.from_numpy(mask.astype(np.uint8)).cuda(), mode=0)
     assert torch.equal(out0, out)
     assert int(flags0.sum()) > 0
+
+
+def test_corrupted_root_image_raises_the_flag_not_a_fault():
+    """The label passes walk parent entries to their roots.  A well-formed union-find image only ever points at an earlier
+    pixel of the same frame, and every walk is FENCED to exactly that (csrc/common.h, walk_ok): a deliberately corrupted
+    root image -- an entry far past the frame, a forward pointer, a two-cycle -- must come back as counts[b] = -1 for that
+    frame, with the other frames of the call labelled as usual, and never as a wild load (round-3 review: the fault in
+    profiles/r03/exp_graph_r3a.log came from a parent array rewritten under a running chain)."""
+    from particle_col_image_segmentation_amd import ops
+    rng = np.random.default_rng(11)
+    H, W = 96, 128
+    masks = (rng.random((5, H, W)) < 0.55).astype(np.uint8)
+    labels = np.stack([orc.label(m.astype(bool)) for m in masks])
+    roots = np.zeros((5, H, W), np.int32)
+    for b in range(5):  # root image = linear index of each component's first pixel + 1
+        flat = labels[b].ravel()
+        first = np.full(int(flat.max()) + 1, -1, np.int64)
+        idx = np.arange(flat.size)
+        order = np.argsort(flat, kind="stable")
+        lab_sorted = flat[order]
+        starts = np.r_[0, np.flatnonzero(np.diff(lab_sorted)) + 1]
+        first[lab_sorted[starts]] = idx[order][starts]
+        r = first[flat] + 1
+        r[flat == 0] = 0
+        roots[b] = r.reshape(H, W)
+    bad = roots.copy()
+    n = H * W
+    fg1 = np.flatnonzero(bad[1].ravel())
+    bad[1].reshape(-1)[fg1[len(fg1) // 2]] = 2_000_000_000          # far past the frame (and the whole buffer)
+    fg3 = np.flatnonzero(bad[3].ravel())
+    i, j = int(fg3[10]), int(fg3[-10])
+    bad[3].reshape(-1)[i] = j + 1                                    # forward pointer ...
+    bad[3].reshape(-1)[j] = i + 1                                    # ... closing a two-cycle
+    bad[4].reshape(-1)[n - 1] = n + 5                                # one past the frame's end, at its last pixel
+    good_l, good_c = ops.compact_labels(torch.from_numpy(roots).cuda())
+    got_l, got_c = ops.compact_labels(torch.from_numpy(bad).cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(good_l.cpu().numpy(), labels)
+    assert good_c.cpu().tolist() == [int(l.max()) for l in labels]
+    assert got_c.cpu().tolist()[1] == -1 and got_c.cpu().tolist()[3] == -1 and got_c.cpu().tolist()[4] == -1
+    for b in (0, 2):  # untouched frames of the same call
+        assert int(got_c[b]) == int(labels[b].max())
+        np.testing.assert_array_equal(got_l[b].cpu().numpy(), labels[b])
