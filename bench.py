@@ -14,10 +14,13 @@ the RCCL all-gather of the ROI table, done once after the timed region.
 The timed region carries no instrumentation (no event records, no counter reads).  By default the batches are launched
 eagerly from 8 host threads with five streams each -- measured faster than hipGraph replay on this chain (replays of
 different graphs overlap less than eager launches from many streams do; the run reports the graph figure next to the
-headline as `graph_replay`, and `--graph` makes it the timed mode).  The JSON line carries `roofline` (dominant kernel;
-HIP events on the launch streams in an instrumented pass of the same chain, same number of batches in flight, right after
-the timed region, plus the same kernel with nothing beside it, `alone`) and `cpu_baseline` (the CPU oracle timed on this
-box's host cores on a bounded sample; reported, not the target).
+headline as `graph_replay`, and `--graph` makes it the timed mode).  The JSON line carries `roofline` (dominant kernel by
+serial time; HIP events on the launch stream in two extra single-stream steps right after the timed region -- the
+reproducible figure -- with the same kernel's duration while 8 batches share the chip as `in_flight`, and `stage_frac` =
+the watershed stage's compulsory 13 B/px over the serial time of all its kernels) and `cpu_baseline` (the CPU oracle timed
+on this box's host cores on a bounded sample; reported, not the target).  `end_to_end` (dataset run incl. table assembly,
+download and gather), `mosaic4096` / `frames2048` (BASELINE configs 4 / 5 shapes), `batch64` / `secondary` (quantised
+input) are further legs of the same run, never `value`.
 """
 import argparse
 import ctypes
@@ -36,10 +39,13 @@ CHAIN_BYTES_PER_PIXEL = 28  # 5 x f32 in + int32 class-CC mask +
 # (kernels of the default chain that can come out on top of the per-kernel table)
 KERNEL_BYTES_PER_PIXEL = {
     "classmap_median_ccl_kernel": 26.0, "ccl_flatten_count_kernel": 4.0, "ccl_relabel_kernel": 8.0,
-    "region_reduce_col_kernel": 24.0, "edt_bits_kernel": 5.125, "edt_row_kernel": 4.0, "edt_reach_kernel": 2.0,
-    "locmax_candidates_kernel": 8.25,
+    "ccl_relabel_quads_kernel": 8.0, "region_sums2_col_kernel": 29.0, "region_stats_col_kernel": 4.0,
+    "edt_bits_kernel": 5.125, "edt_row_kernel": 4.0, "edt_reach_kernel": 2.0, "locmax_candidates_kernel": 8.25,
     "ws_relax_kernel": 12.0, "ws_uf_tile_kernel": 13.0, "ws_uf_label4_kernel": 9.0, "ws_exact_kernel": 21.0,
 }
+# the watershed STAGE's compulsory traffic: boundary plane 4 + markers 4 + mask 1 in, labels 4 out (once per pixel,
+# however often the relaxation revisits a tile): what `roofline.stage_frac` prices the stage's serial kernel time against
+WS_STAGE_BYTES_PER_PIXEL = 13.0
 
 
 def parse_args():
@@ -73,6 +79,8 @@ def parse_args():
                     help="frames of the SECONDARY leg (0 = off): one batch with the boundary plane quantised to k/100, the "
                          "realistic ilastik-random-forest input on which every frame floods through ties; reported as "
                          "\"secondary\" next to the headline, never as `value`")
+    ap.add_argument("--no-shape-legs", action="store_true",
+                    help="skip the `mosaic4096` (BASELINE config 4) and `frames2048` (config 5's frame shape) legs")
     ap.add_argument("--levels", type=int, default=0,
                     help="NOT the headline workload: quantise the boundary plane to k/LEVELS (random-forest-like vote "
                          "fractions); every frame then floods through ties and takes the watershed's exact path")
@@ -317,6 +325,54 @@ def batch64_leg(args, stack, cell_types):
             "frames": n, "tie_fallback_frames": int(res["tie_flags"].sum().item()), "parity_checked_frames": checked}
 
 
+def shape_leg(name, B, H, W, cell_types, lib, dev, steps, seed):
+    """BASELINE config 4 (one 4096 x 4096 x 5 mosaic) / config 5's frame shape (2048 x 2048 x 5): the full chain on that
+    shape -- throughput with the default pipeline (8 batches in flight), the latency of ONE batch with nothing beside it,
+    the serial kernel table's top five, and frame 0 against the oracle.  Never `value`."""
+    import torch
+    from oracle import parity
+    from particle_col_image_segmentation_amd import synth
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline
+    stack = synth.gen_batch_torch(seed, B, H, W, dev)
+    cap = max(1024, (H * W) // 64)
+    pipe = FramePipeline(cell_types)
+    for _ in range(pipe.lanes + 2):
+        res = pipe.run(stack)
+    pipe.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = pipe.run(stack)
+    pipe.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    if int(res["overflow"].sum().item()) or int(res["ws_overflow"].sum().item()):
+        raise SystemExit("bench.py: region table capacity exceeded (%s leg)" % name)
+    solo = FramePipeline(cell_types, overlap=False)
+    solo.run(stack).synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        one = solo.run(stack)
+    torch.cuda.synchronize()
+    lat = 1e3 * (time.perf_counter() - t0) / 3
+    kernels, _, _ = _timing_pass(lib, lambda: [solo.run(stack) for _ in range(2)], torch.cuda.synchronize)
+    top = sorted(kernels.items(), key=lambda kv: -kv[1][1])[:5]
+    total = sum(v[1] for v in kernels.values()) / 2
+    refs, _, _ = parity.run_oracle(stack[:1].cpu().numpy(), cell_types, merged=True, processes=1)
+    checked = parity.compare(one, [0], refs, sums_rtol=1e-6)
+    out = {"workload": "%d x %dx%dx5 float32 per step, full kernel chain, inputs resident in HBM, region-table capacity %d"
+                       % (B, H, W, cap),
+           "value": round(B * H * W / ms / 1e3, 1), "unit": "Mpixels/s", "steps": steps, "ms_per_step": round(ms, 3),
+           "launch": "eager launches from %d host threads (that many batches in flight)" % pipe.lanes,
+           "one_batch_alone_ms": round(lat, 3), "one_batch_alone_Mpixels_per_s": round(B * H * W / lat / 1e3, 1),
+           "serial_kernel_ms_per_step": round(total, 3),
+           "top_kernels_serial": [{"kernel": k.split("(")[0], "launches_per_step": c / 2, "ms_per_step": round(t / 2, 3)}
+                                  for k, (c, t) in top],
+           "tie_fallback_frames": int(one["tie_flags"].sum().item()), "parity_checked_frames": checked}
+    del pipe, solo, res, one, stack
+    torch.cuda.empty_cache()
+    return out
+
+
 def _run(args):
     import torch
     import torch.distributed as dist
@@ -432,7 +488,12 @@ def _run(args):
         if args.kernel_table:
             for name, (calls, ms) in sorted(kernels.items(), key=lambda kv: -kv[1][1]):
                 print("%10.3f ms %7d launches %9.2f us/launch  %s" % (ms, calls, 1e3 * ms / calls, name), file=sys.stderr)
-        dom_name, (dom_calls, dom_ms) = max(kernels.items(), key=lambda kv: kv[1][1])
+        # the dominant kernel: by its time with nothing beside it (the serial table) when that table exists
+        rank_table = alone[0] if alone is not None else kernels
+        dom_name = max(rank_table.items(), key=lambda kv: kv[1][1])[0]
+        if dom_name not in kernels:
+            dom_name = max(kernels.items(), key=lambda kv: kv[1][1])[0]
+        dom_calls, dom_ms = kernels[dom_name]
         short = dom_name.split("<")[0].split(" ")[0].strip("()")
         bpp = KERNEL_BYTES_PER_PIXEL.get(short, 0.0)
 
@@ -451,12 +512,19 @@ def _run(args):
                     "algorithmic_bytes_per_launch": round(nbytes), "pixels_per_launch": round(units),
                     "achieved": round(nbytes / avg_s / 1e9, 2), "frac": round(nbytes / avg_s / 1e9 / HBM_PEAK_GBS, 5)}
 
-        main_block = launch_block(kernels, tiles_i, launches_i, steps_i)
-        alone_block = None
+        insitu_block = launch_block(kernels, tiles_i, launches_i, steps_i)
+        insitu_block["how"] = ("%d steps of the same chain with %d batches in flight (the launches of a step then share the CUs "
+                               "with seven other batches: a launch's duration here is a concurrency figure, not a kernel time -- "
+                               "launches_per_step x avg_launch_us may exceed ms_per_step)" % (steps_i, pipe.lanes))
+        main_block, stage_frac, ws_serial_ms = insitu_block, None, None
         if alone is not None and dom_name in alone[0]:
-            alone_block = launch_block(alone[0], alone[1], alone[2], alone[3])
-            alone_block["how"] = "2 extra steps on one stream after the timed region"
-            alone_block["serial_kernel_ms_per_step"] = round(sum(ms for _, ms in alone[0].values()) / alone[3], 3)
+            # THE roofline figure: the kernel with nothing beside it (one stream), reproducible from profiles/
+            main_block = launch_block(alone[0], alone[1], alone[2], alone[3])
+            main_block["serial_kernel_ms_per_step"] = round(sum(ms for _, ms in alone[0].values()) / alone[3], 3)
+            # the watershed stage as a whole: its compulsory bytes (13 B/px, once) over the serial time of all its kernels
+            ws_serial_ms = sum(ms for name, (_, ms) in alone[0].items() if name.lstrip("(").startswith("ws_")) / alone[3]
+            if ws_serial_ms > 0:
+                stage_frac = WS_STAGE_BYTES_PER_PIXEL * B * H * W / (ws_serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         total_kernel_ms = sum(ms for _, ms in kernels.values())
         value = world * B * H * W * args.steps / elapsed / 1e6
         traffic = None
@@ -479,10 +547,13 @@ def _run(args):
                        "roi_table_all_gather_ms": round(gather_ms, 3)},
             "roofline": dict({"bound": "hbm", "kernel": short, "algorithmic_bytes_per_pixel": bpp}, **main_block,
                              **{"peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,
-                                "how": "HIP events on the launch streams, %d steps of the same chain with %d batches in flight, launched "
-                                       "eagerly right after the timed region (a graph replay cannot be bracketed per kernel)"
-                                       % (steps_i, pipe.lanes),
-                                "alone": alone_block,
+                                "how": "HIP events on the launch stream, 2 extra steps of the same chain on ONE stream right after "
+                                       "the timed region (nothing beside the kernel); `in_flight` = the same kernel while 8 batches "
+                                       "share the chip",
+                                "in_flight": insitu_block if main_block is not insitu_block else None,
+                                "stage": "watershed (ws_* kernels): %.1f B/px compulsory, once" % WS_STAGE_BYTES_PER_PIXEL,
+                                "stage_serial_ms_per_step": None if ws_serial_ms is None else round(ws_serial_ms, 3),
+                                "stage_frac": None if stage_frac is None else round(stage_frac, 5),
                                 "share_of_kernel_time": round(dom_ms / total_kernel_ms, 4),
                                 "chain_bytes_per_pixel": CHAIN_BYTES_PER_PIXEL,
                                 "chain_achieved_GBps": round(CHAIN_BYTES_PER_PIXEL * value / world / 1e3, 3),
@@ -498,6 +569,9 @@ def _run(args):
                 out["graph_replay"] = graph_leg(args, stack, ct, 1e3 * elapsed / args.steps)
             if args.batch64_frames > 0:
                 out["batch64"] = batch64_leg(args, stack, ct)
+            if not args.no_shape_legs:
+                out["mosaic4096"] = shape_leg("mosaic4096", 1, 4096, 4096, ct, lib, dev, 16, 40_000)
+                out["frames2048"] = shape_leg("frames2048", 16, 2048, 2048, ct, lib, dev, 8, 50_000)
             if args.secondary_batch > 0:
                 out["secondary"] = secondary_leg(args, stack, ct, pipe)
         line = json.dumps(out)

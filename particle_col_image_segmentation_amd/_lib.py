@@ -96,11 +96,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # PCSEG_LIB: an A/B build of the SAME library (particle_col_image_segmentation_amd.build.build(out_dir=...)), for
+    # same-box kernel comparisons; never a different implementation -- the prototypes below must all resolve
+    path = os.environ.get("PCSEG_LIB") or LIB_PATH
+    if not os.path.exists(path):
         raise PcsegError(
             "libpcseg.so is not built (%s). Run `python -m particle_col_image_segmentation_amd.build` "
-            "or __graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "or __graft_entry__.build(); there is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res

@@ -18,16 +18,21 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, out_dir=None, extra_flags=None):
+    """``out_dir`` / ``extra_flags``: an A/B variant of the library (``-D`` tunables) built beside the product's, e.g. into
+    ``ab/<name>/libpcseg.so`` -- loaded with ``PCSEG_LIB=<path>`` (``_lib.load``), see profiles/r04/make_ab.sh."""
+    lib_path = LIB if out_dir is None else os.path.join(out_dir, "libpcseg.so")
+    if out_dir is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    obj_dir = os.path.join(HERE, "build") if out_dir is None else os.path.join(out_dir, "build")
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = (extra_flags if extra_flags is not None else os.environ.get("PCSEG_EXTRA_FLAGS", "")).split()
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + os.environ.get("PCSEG_EXTRA_FLAGS", "").split() + [
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + flags + [
             "-c", os.path.join(CSRC, src), "-o", obj]  # PCSEG_EXTRA_FLAGS: -D tunables for A/B builds (profiles/ab_compare.sh)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -37,9 +42,9 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     subprocess.check_call(cmd)
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":

@@ -76,6 +76,26 @@ __device__ __forceinline__ void ws_load_tile(T *s, const T *__restrict__ g, int 
 // monotone (min / 0->label), so concurrent sweeps may read each other's half-finished values: a stale read only
 // costs another outer iteration.  One sweep carries information across the whole tile, so the number of outer
 // iterations is the number of direction changes of the dependency paths, not their length.
+// LDS cell of the relaxation: (level, value) as one 64-bit word.  PCSEG_WS_MIN64 (A/B, round 4) puts the LEVEL IN THE HIGH
+// dword: the cell as a 64-bit integer is then ordered by its level (the value half never changes), and the sweep's atomic can
+// be ONE ds_min_u64 on the whole cell -- banked like ds_read_b64 over 64 dwords, where the lanes of a wavefront sweep (an even
+// number of dwords apart, 8-byte cells) never collide -- instead of a ds_min_u32 on the level dword, which the 32-dword
+// banking of 4-byte operations serves 2-way conflicted (46 % of this kernel's LDS cycles, profiles/r03_pmc_sq_summary.txt).
+#ifndef PCSEG_WS_MIN64
+#define PCSEG_WS_MIN64 0
+#endif
+#if PCSEG_WS_MIN64
+#define WS_CELL(level, value) make_uint2((value), (level))
+#define WS_LEVEL(cell) ((cell).y)
+#define WS_VALUE(cell) ((cell).x)
+constexpr int WS_LW = 1;  // dword of the level inside a cell
+#else
+#define WS_CELL(level, value) make_uint2((level), (value))
+#define WS_LEVEL(cell) ((cell).x)
+#define WS_VALUE(cell) ((cell).y)
+constexpr int WS_LW = 0;
+#endif
+
 struct SweepLine {
     int start, step;  // LDS index of the halo element in front of the line, and the index step along the line
 };
@@ -175,7 +195,7 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
 {
     unsigned *sLw = reinterpret_cast<unsigned *>(sLV);  // the L half of element i is word 2 * i
     unsigned diff = 0;  // != 0 once a cell of this line was lowered
-    unsigned prev = sLV[start].x;
+    unsigned prev = WS_LEVEL(sLV[start]);
     int base = start + STEP;
 #pragma unroll 1
     for (int k0 = 0; k0 < 64; k0 += WS_BATCH, base += WS_BATCH * STEP) {
@@ -221,7 +241,7 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
             // value <= L holds for every cell (seeds start at their value, everything else at +inf, and a level never
             // drops below its cell's value), so min(L, max(value, prev)) is the MEDIAN of the three: one v_med3_u32 on
             // the serial chain instead of v_max followed by v_min
-            const unsigned cur = lv[j].x, v = lv[j].y;
+            const unsigned cur = WS_LEVEL(lv[j]), v = WS_VALUE(lv[j]);
             nw[j] = min(max(v, prev), max(min(v, prev), cur));
             batch_diff |= cur ^ nw[j];
             prev = nw[j];
@@ -231,7 +251,7 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
             // word measured 13 % slower, a compare + masked store 10 %), and still monotone when another wave lowered
             // the cell since the batch was read
 #pragma unroll
-            for (int j = 0; j < WS_BATCH; ++j) atomicMin(&sLw[2 * (base + j * STEP)], nw[j]);
+            for (int j = 0; j < WS_BATCH; ++j) atomicMin(&sLw[2 * (base + j * STEP) + WS_LW], nw[j]);
             diff |= batch_diff;
         }
     }
@@ -271,20 +291,20 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
     {   // the first row takes the halo row's levels before the sweep (lane = column): lane 0 then needs no `up`
         constexpr int fr = DR > 0 ? 1 : WS_T, hr = DR > 0 ? 0 : WS_T + 1;
         const uint2 c = sLV[fr * P + 1 + lane];
-        const unsigned h = sLV[hr * P + 1 + lane].x;
-        const unsigned nw = min(c.x, max(c.y, h));
-        atomicMin(&sLw[2 * (fr * P + 1 + lane)], nw);
-        diff |= __ballot(nw != c.x);
+        const unsigned h = WS_LEVEL(sLV[hr * P + 1 + lane]);
+        const unsigned nw = min(WS_LEVEL(c), max(WS_VALUE(c), h));
+        atomicMin(&sLw[2 * (fr * P + 1 + lane) + WS_LW], nw);
+        diff |= __ballot(nw != WS_LEVEL(c));
     }
     const int lr = DR > 0 ? lane + 1 : WS_T - lane;  // the lane's row (LDS coordinates 1 .. 64)
     const uint2 *row = sLV + lr * P;
-    const unsigned halo = row[DC > 0 ? 0 : WS_T + 1].x;
+    const unsigned halo = WS_LEVEL(row[DC > 0 ? 0 : WS_T + 1]);
     const int u0 = (0 - lane) & 63;                   // cyclic position at step 0
     // what the first step finds behind it: the row's cell at position u0 - 1 as it is now
-    unsigned left = row[DC > 0 ? u0 : WS_T + 1 - u0].x;  // (u0 == 0: replaced by the halo cell at the first step anyway)
+    unsigned left = WS_LEVEL(row[DC > 0 ? u0 : WS_T + 1 - u0]);  // (u0 == 0: replaced by the halo cell at the first step anyway)
     // what the next lane finds above its first cell: this row's cell at THAT lane's first position
     const int un = (0 - (lane + 1)) & 63;
-    unsigned prev = row[DC > 0 ? 1 + un : WS_T - un].x;
+    unsigned prev = WS_LEVEL(row[DC > 0 ? 1 + un : WS_T - un]);
     // byte address of the row's cell at cyclic position 0, and the step per position
     const unsigned a0 = (unsigned)(uintptr_t)(row + (DC > 0 ? 1 : WS_T));
 #pragma unroll 1
@@ -322,10 +342,11 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
             const unsigned long long at0 = (1ull << k) << j0;  // the lane that is at position 0 now restarts from its halo cell
             unsigned lf;
             asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lf) : "v"(left), "v"(halo), "s"(at0));
-            const unsigned cur = t[k].x, v = t[k].y;
+            const unsigned cur = PCSEG_WS_MIN64 ? t[k].y : t[k].x, v = PCSEG_WS_MIN64 ? t[k].x : t[k].y;
             const unsigned m = min(up, lf);
             const unsigned cand = min(max(v, m), max(min(v, m), cur));  // median(value, m, cur) = min(cur, max(value, m))
             wr[k] = cand;
+            if (PCSEG_WS_MIN64) t[k].y = cand;  // the cell as it should be: (value, lowered level), the 64-bit atomic's operand
 #if PCSEG_WS_SWEEP_MASKS == 0
             lane_diff |= cur ^ cand;
             lowered[k] = true;
@@ -343,15 +364,133 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
             // unconditional LDS atomic min per cell of a changed batch (variant 2 predicates it per lane: measured slower);
             // still monotone when another wave lowered the cell since the batch was read.  (The level is the first word of
             // the cell: the read's address and offset serve the atomic as they are.)
+#if PCSEG_WS_MIN64
+#define PCSEG_DS_MIN(k)                                                                                                             \
+            if (PCSEG_WS_SWEEP_MASKS < 2 || lowered[k])                                                                                 \
+                asm volatile("ds_min_u64 %0, %1 offset:%2" : : "v"(ba[k]), "v"(t[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
+#else
 #define PCSEG_DS_MIN(k)                                                                                                             \
             if (PCSEG_WS_SWEEP_MASKS < 2 || lowered[k])                                                                                 \
                 asm volatile("ds_min_u32 %0, %1 offset:%2" : : "v"(ba[k]), "v"(wr[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
+#endif
             PCSEG_DS_MIN(0) PCSEG_DS_MIN(1) PCSEG_DS_MIN(2) PCSEG_DS_MIN(3)
             PCSEG_DS_MIN(4) PCSEG_DS_MIN(5) PCSEG_DS_MIN(6) PCSEG_DS_MIN(7)
 #undef PCSEG_DS_MIN
             diff |= batch_diff;
         }
     }
+    return diff != 0;
+}
+
+// The same sweep with the LDS reads of batch j + 1 in flight while batch j is computed (PCSEG_WS_PIPE, round 4).  The plain
+// form issues its eight reads and waits for all of them before the first of its ~50 vector instructions, eight times a
+// sweep; with four waves per SIMD all doing the same, neither the LDS (56 % busy) nor the VALU (17 %) was saturated
+// (profiles/r03_pmc_sq_summary.txt: 38 % of the wave cycles waiting, 26 % issue-stalled).  The loop is unrolled by two so that
+// the two register sets swap roles without moves.  A batch's cells are read BEFORE the previous batch's atomics are
+// issued: they are other cells of the lane's own row (nothing this wave writes in between), and what another wave lowers
+// meanwhile is picked up an iteration later, which the monotone update tolerates -- as everywhere in these sweeps.
+// LDS operations return in order: behind [reads of the next batch][atomics of this batch] `lgkmcnt(8)` says the reads are
+// there; without atomics it has to be `lgkmcnt(0)`.
+#ifndef PCSEG_WS_PIPE
+#define PCSEG_WS_PIPE 0
+#endif
+template <int DR, int DC, int P>
+__device__ __forceinline__ bool ws_quadrant_sweep_pipe(uint2 *sLV, int lane)
+{
+    unsigned *sLw = reinterpret_cast<unsigned *>(sLV);
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    unsigned long long diff = 0;
+    const int lr = DR > 0 ? lane + 1 : WS_T - lane;  // the lane's row (LDS coordinates 1 .. 64)
+    const uint2 *row = sLV + lr * P;
+    const int u0 = (0 - lane) & 63;                   // cyclic position at step 0
+    const unsigned a0 = (unsigned)(uintptr_t)(row + (DC > 0 ? 1 : WS_T));
+    unsigned baA[8], baB[8];
+    u2v tA[8], tB[8];
+#define PCSEG_ISSUE(BA, T, J0)                                                                                                 \
+    {                                                                                                                          \
+        const int ub_ = (u0 + (J0)) & 63;                                                                                      \
+        const unsigned base_a_ = DC > 0 ? a0 + 8u * (unsigned)ub_ : a0 - 8u * (unsigned)ub_ - 56u;                             \
+        const unsigned base_b_ = DC > 0 ? base_a_ - 512u : base_a_ + 512u;                                                     \
+        PCSEG_ISSUE1(BA, T, J0, 0) PCSEG_ISSUE1(BA, T, J0, 1) PCSEG_ISSUE1(BA, T, J0, 2) PCSEG_ISSUE1(BA, T, J0, 3)            \
+        PCSEG_ISSUE1(BA, T, J0, 4) PCSEG_ISSUE1(BA, T, J0, 5) PCSEG_ISSUE1(BA, T, J0, 6) PCSEG_ISSUE1(BA, T, J0, 7)            \
+        __builtin_amdgcn_sched_barrier(0); /* all eight reads go out BEFORE the batch that is computed under them */           \
+    }
+#define PCSEG_ISSUE1(BA, T, J0, k)                                                                                             \
+        {                                                                                                                      \
+            const unsigned long long wrapped_ = (((1ull << (k)) - 1ull) << 1) << (J0);  /* lanes J0 + 1 .. J0 + k */           \
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(BA[k]) : "v"(base_a_), "v"(base_b_), "s"(wrapped_));                  \
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(T[k]) : "v"(BA[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))));     \
+        }
+    // batch 0's reads go out first; the halo-row step below (its own read, atomic and wait) runs under them
+    PCSEG_ISSUE(baA, tA, 0)
+    {   // the first row takes the halo row's levels before the sweep (lane = column): lane 0 then needs no `up`
+        constexpr int fr = DR > 0 ? 1 : WS_T, hr = DR > 0 ? 0 : WS_T + 1;
+        const uint2 c = sLV[fr * P + 1 + lane];
+        const unsigned h = WS_LEVEL(sLV[hr * P + 1 + lane]);
+        const unsigned nw = min(WS_LEVEL(c), max(WS_VALUE(c), h));
+        atomicMin(&sLw[2 * (fr * P + 1 + lane) + WS_LW], nw);
+        diff |= __ballot(nw != WS_LEVEL(c));
+    }
+    const unsigned halo = WS_LEVEL(row[DC > 0 ? 0 : WS_T + 1]);
+    unsigned left = WS_LEVEL(row[DC > 0 ? u0 : WS_T + 1 - u0]);
+    const int un = (0 - (lane + 1)) & 63;
+    unsigned prev = WS_LEVEL(row[DC > 0 ? 1 + un : WS_T - un]);
+    // the three reads above are "used" HERE: the compiler's wait for them then sits in front of the loop.  Left to the first
+    // real use -- inside the loop -- it becomes an s_waitcnt lgkmcnt(0) at the loop head (the wait-count pass cannot count
+    // across the back edge), i.e. a drain of the reads this loop keeps in flight, once per iteration
+    asm volatile("" : "+v"(left), "+v"(prev) : "v"(halo));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tA[0]), "+v"(tA[1]), "+v"(tA[2]), "+v"(tA[3]), "+v"(tA[4]), "+v"(tA[5]), "+v"(tA[6]), "+v"(tA[7]));
+    // (lane 0 of a row-0 wave re-reads the cell the halo-row step has just lowered one batch late at worst: monotone)
+#define PCSEG_COMPUTE(BA, T, TN, J0, HAVE_NEXT)                                                                                \
+    {                                                                                                                          \
+        unsigned wr_[8];                                                                                                       \
+        unsigned long long batch_diff_ = 0;                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                                        \
+            const unsigned up_ = (unsigned)__builtin_amdgcn_update_dpp((int)WS_INF, (int)prev, 0x138, 0xF, 0xF, false);        \
+            const unsigned long long at0_ = (1ull << k) << (J0);                                                               \
+            unsigned lf_;                                                                                                      \
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lf_) : "v"(left), "v"(halo), "s"(at0_));                              \
+            const unsigned cur_ = PCSEG_WS_MIN64 ? T[k].y : T[k].x, v_ = PCSEG_WS_MIN64 ? T[k].x : T[k].y;                     \
+            const unsigned m_ = min(up_, lf_);                                                                                 \
+            const unsigned cand_ = min(max(v_, m_), max(min(v_, m_), cur_));                                                   \
+            wr_[k] = cand_;                                                                                                    \
+            if (PCSEG_WS_MIN64) T[k].y = cand_;                                                                                \
+            batch_diff_ |= __ballot(cur_ != cand_);                                                                            \
+            left = cand_;                                                                                                      \
+            prev = cand_;                                                                                                      \
+        }                                                                                                                      \
+        if (batch_diff_ != 0) {                                                                                                \
+            PCSEG_PMIN(BA, T, wr_, 0) PCSEG_PMIN(BA, T, wr_, 1) PCSEG_PMIN(BA, T, wr_, 2) PCSEG_PMIN(BA, T, wr_, 3)            \
+            PCSEG_PMIN(BA, T, wr_, 4) PCSEG_PMIN(BA, T, wr_, 5) PCSEG_PMIN(BA, T, wr_, 6) PCSEG_PMIN(BA, T, wr_, 7)            \
+            diff |= batch_diff_;                                                                                               \
+            if (HAVE_NEXT)                                                                                                     \
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(TN[0]), "+v"(TN[1]), "+v"(TN[2]), "+v"(TN[3]), "+v"(TN[4]), "+v"(TN[5]), "+v"(TN[6]), "+v"(TN[7])); \
+        } else if (HAVE_NEXT) {                                                                                                \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(TN[0]), "+v"(TN[1]), "+v"(TN[2]), "+v"(TN[3]), "+v"(TN[4]), "+v"(TN[5]), "+v"(TN[6]), "+v"(TN[7])); \
+        }                                                                                                                      \
+    }
+#if PCSEG_WS_MIN64
+#define PCSEG_PMIN(BA, T, WR, k) \
+            asm volatile("ds_min_u64 %0, %1 offset:%2" : : "v"(BA[k]), "v"(T[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
+#else
+#define PCSEG_PMIN(BA, T, WR, k) \
+            asm volatile("ds_min_u32 %0, %1 offset:%2" : : "v"(BA[k]), "v"(WR[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
+#endif
+#pragma unroll 1
+    for (int j0 = 0; j0 < WS_T; j0 += 16) {
+        PCSEG_ISSUE(baB, tB, j0 + 8)
+        PCSEG_COMPUTE(baA, tA, tB, j0, true)
+        if (j0 + 16 < WS_T) {
+            PCSEG_ISSUE(baA, tA, j0 + 16)
+            PCSEG_COMPUTE(baB, tB, tA, j0 + 8, true)
+        } else {
+            PCSEG_COMPUTE(baB, tB, tA, j0 + 8, false)
+        }
+    }
+#undef PCSEG_ISSUE
+#undef PCSEG_ISSUE1
+#undef PCSEG_COMPUTE
+#undef PCSEG_PMIN
     return diff != 0;
 }
 
@@ -407,9 +546,9 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
     // (L, value) of a pixel before any relaxation
     auto initial = [&](int r, int c) -> uint2 {
         const int64_t g = fbase + rowoff(r, W) + c;
-        if (!in.mask[g]) return make_uint2(WS_INF, WS_INF);
+        if (!in.mask[g]) return WS_CELL(WS_INF, WS_INF);
         const unsigned v = ws_key(in.img[(int64_t)b * in.frame_stride + rowoff(r, W) + c]);
-        return make_uint2(in.markers[g] != 0 ? v : WS_INF, v);
+        return WS_CELL(in.markers[g] != 0 ? v : WS_INF, v);
     };
     if (in.vec) {
         // The tile load is ONE batch of loads per thread, not a loop of dependent round trips: every access goes to a
@@ -457,7 +596,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
                         const bool msk = inside && ((k4[t] >> (8 * j)) & 255u) != 0;
                         key[j] = msk ? ws_key(fv[j]) : WS_INF;
                         lab[j] = msk ? mv[j] : 0;
-                        sLV[lr * P + 1 + 4 * q + j] = make_uint2(lab[j] != 0 ? key[j] : WS_INF, key[j]);
+                        sLV[lr * P + 1 + 4 * q + j] = WS_CELL(lab[j] != 0 ? key[j] : WS_INF, key[j]);
                     }
                     if (inside && lr >= 1 && lr <= T) {  // own pixels: publish value keys and seed labels
                         const int64_t g = fbase + rowoff(r, W) + c;
@@ -469,7 +608,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             if (halo_thread) {
                 const bool msk = h_in && hk != 0;
                 const unsigned key = msk ? ws_key(hf) : WS_INF;
-                sLV[h_lr * P + h_lc] = make_uint2(msk && hm != 0 ? key : WS_INF, key);
+                sLV[h_lr * P + h_lc] = WS_CELL(msk && hm != 0 ? key : WS_INF, key);
             }
         } else {
             uint4 l4[TRIPS], v4[TRIPS];
@@ -490,30 +629,29 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
                     const int r = r0 + lr - 1, c = c0 + 4 * q;
                     const bool inside = r >= 0 && r < H && c >= 0 && c < W;
                     uint2 *dst = sLV + lr * P + 1 + 4 * q;
-                    dst[0] = inside ? make_uint2(l4[t].x, v4[t].x) : make_uint2(WS_INF, WS_INF);
-                    dst[1] = inside ? make_uint2(l4[t].y, v4[t].y) : make_uint2(WS_INF, WS_INF);
-                    dst[2] = inside ? make_uint2(l4[t].z, v4[t].z) : make_uint2(WS_INF, WS_INF);
-                    dst[3] = inside ? make_uint2(l4[t].w, v4[t].w) : make_uint2(WS_INF, WS_INF);
+                    dst[0] = inside ? WS_CELL(l4[t].x, v4[t].x) : WS_CELL(WS_INF, WS_INF);
+                    dst[1] = inside ? WS_CELL(l4[t].y, v4[t].y) : WS_CELL(WS_INF, WS_INF);
+                    dst[2] = inside ? WS_CELL(l4[t].z, v4[t].z) : WS_CELL(WS_INF, WS_INF);
+                    dst[3] = inside ? WS_CELL(l4[t].w, v4[t].w) : WS_CELL(WS_INF, WS_INF);
                 }
             }
-            if (halo_thread) sLV[h_lr * P + h_lc] = h_in ? make_uint2(hl, hv) : make_uint2(WS_INF, WS_INF);
+            if (halo_thread) sLV[h_lr * P + h_lc] = h_in ? WS_CELL(hl, hv) : WS_CELL(WS_INF, WS_INF);
         }
     } else
     for (int i = tid; i < S * S; i += NT) {
         int lr = i / S, lc = i % S;
         int r = r0 + lr - 1, c = c0 + lc - 1;
-        uint2 lv = make_uint2(WS_INF, WS_INF);
+        uint2 lv = WS_CELL(WS_INF, WS_INF);
         if (r >= 0 && r < H && c >= 0 && c < W) {
             if (FIRST) {
                 lv = initial(r, c);
                 if (lr >= 1 && lr <= T && lc >= 1 && lc <= T) {  // own pixels: publish value key and seed label
                     const int64_t g = fbase + rowoff(r, W) + c;
-                    val[g] = lv.y;
-                    in.out[g] = lv.y != WS_INF ? in.markers[g] : 0;
+                    val[g] = WS_VALUE(lv);
+                    in.out[g] = WS_VALUE(lv) != WS_INF ? in.markers[g] : 0;
                 }
             } else {
-                lv.x = L[fbase + rowoff(r, W) + c];
-                lv.y = val[fbase + rowoff(r, W) + c];
+                lv = WS_CELL(L[fbase + rowoff(r, W) + c], val[fbase + rowoff(r, W) + c]);
             }
         }
         sLV[lr * P + lc] = lv;
@@ -527,7 +665,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
     const int qy = e < 4 ? (e >> 1) : (e & 1), qx = e < 4 ? (e & 1) : ((e >> 1) & 1);
     const int rim_lr = e < 4 ? (qy ? T : 1) : qy * G::HE + ej + 1;
     const int rim_lc = e < 4 ? qx * G::HE + ej + 1 : (qx ? T : 1);
-    const unsigned rim_before = rim_thread ? sLV[rim_lr * P + rim_lc].x : 0u;
+    const unsigned rim_before = rim_thread ? WS_LEVEL(sLV[rim_lr * P + rim_lc]) : 0u;
     // wave = (direction, group of 64 lines, 64-cell segment of the lines): the segments of a line are swept at the same
     // time, each starting from the cell in front of it -- its neighbour segment's last cell, or the halo
     const int wave = tid >> 6, lane = tid & 63;
@@ -541,7 +679,12 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
         // one code path per direction: the step is a compile-time constant there, so the LDS addresses of a batch are
         // base + constant
         bool changed;
-        if constexpr (PCSEG_WS_FSM && T == 64) {
+        if constexpr (PCSEG_WS_FSM && T == 64 && PCSEG_WS_PIPE) {
+            if (dir == 0) changed = ws_quadrant_sweep_pipe<1, 1, P>(sLV, lane);
+            else if (dir == 1) changed = ws_quadrant_sweep_pipe<1, -1, P>(sLV, lane);
+            else if (dir == 2) changed = ws_quadrant_sweep_pipe<-1, 1, P>(sLV, lane);
+            else changed = ws_quadrant_sweep_pipe<-1, -1, P>(sLV, lane);
+        } else if constexpr (PCSEG_WS_FSM && T == 64) {
             if (dir == 0) changed = ws_quadrant_sweep<1, 1, P>(sLV, lane);
             else if (dir == 1) changed = ws_quadrant_sweep<1, -1, P>(sLV, lane);
             else if (dir == 2) changed = ws_quadrant_sweep<-1, 1, P>(sLV, lane);
@@ -561,7 +704,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
         const int r = r0 + rim_lr - 1, c = c0 + rim_lc - 1;
         // a tile that stopped early is not consistent inside: all four corner tiles have to look at it again
         bool ch = rim_thread && capped;
-        if (rim_thread && !capped && r >= 0 && r < H && c >= 0 && c < W) ch = sLV[rim_lr * P + rim_lc].x != rim_before;
+        if (rim_thread && !capped && r >= 0 && r < H && c >= 0 && c < W) ch = WS_LEVEL(sLV[rim_lr * P + rim_lc]) != rim_before;
         // the lanes of this thread's half edge inside its wave
         const unsigned long long mine = G::HE >= 64 ? ~0ull : (((1ull << (G::HE & 63)) - 1ull) << ((tid & 63) / G::HE * G::HE));
         const unsigned long long edge_changed = __ballot(ch) & mine;
@@ -581,14 +724,14 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             const int r = r0 + lr, c = c0 + 4 * q;
             const uint2 *src = sLV + (lr + 1) * P + 1 + 4 * q;
             if (r >= 0 && r < H && c >= 0 && c < W)
-                *reinterpret_cast<uint4 *>(L + fbase + rowoff(r, W) + c) = make_uint4(src[0].x, src[1].x, src[2].x, src[3].x);
+                *reinterpret_cast<uint4 *>(L + fbase + rowoff(r, W) + c) = make_uint4(WS_LEVEL(src[0]), WS_LEVEL(src[1]), WS_LEVEL(src[2]), WS_LEVEL(src[3]));
         }
         return;
     }
     for (int i = tid; i < T * T; i += NT) {
         int lr = i / T, lc = i % T;
         int r = r0 + lr, c = c0 + lc;
-        if (r >= 0 && r < H && c >= 0 && c < W) L[fbase + rowoff(r, W) + c] = sLV[(lr + 1) * P + lc + 1].x;
+        if (r >= 0 && r < H && c >= 0 && c < W) L[fbase + rowoff(r, W) + c] = WS_LEVEL(sLV[(lr + 1) * P + lc + 1]);
     }
 }
 
