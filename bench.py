@@ -365,7 +365,7 @@ def shape_leg(name, B, H, W, cell_types, lib, dev, steps, seed):
            "launch": "eager launches from %d host threads (that many batches in flight)" % pipe.lanes,
            "one_batch_alone_ms": round(lat, 3), "one_batch_alone_Mpixels_per_s": round(B * H * W / lat / 1e3, 1),
            "serial_kernel_ms_per_step": round(total, 3),
-           "top_kernels_serial": [{"kernel": k.split("(")[0], "launches_per_step": c / 2, "ms_per_step": round(t / 2, 3)}
+           "top_kernels_serial": [{"kernel": k.lstrip("(").split(")")[0].split(" [")[0], "launches_per_step": c / 2, "ms_per_step": round(t / 2, 3)}
                                   for k, (c, t) in top],
            "tie_fallback_frames": int(one["tie_flags"].sum().item()), "parity_checked_frames": checked}
     del pipe, solo, res, one, stack
@@ -545,11 +545,12 @@ def _run(args):
                        "tie_fallback_frames_last_step": tie_frames, "reference_nan_frames_rank0": nan_frames,
                        "gathered_roi_rows": n_rois, "table_assembly_ms_last_batch": round(table_ms, 3),
                        "roi_table_all_gather_ms": round(gather_ms, 3)},
-            "roofline": dict({"bound": "hbm", "kernel": short, "algorithmic_bytes_per_pixel": bpp}, **main_block,
+            "roofline": dict({"bound": "hbm", "kernel": short, "algorithmic_bytes_per_pixel": bpp},
+                             **{k: v for k, v in main_block.items() if k != "how"},
                              **{"peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic,
-                                "how": "HIP events on the launch stream, 2 extra steps of the same chain on ONE stream right after "
-                                       "the timed region (nothing beside the kernel); `in_flight` = the same kernel while 8 batches "
-                                       "share the chip",
+                                "how": ("HIP events on the launch stream, 2 extra steps of the same chain on ONE stream right after "
+                                        "the timed region (nothing beside the kernel); `in_flight` = the same kernel while 8 batches "
+                                        "share the chip") if main_block is not insitu_block else insitu_block["how"],
                                 "in_flight": insitu_block if main_block is not insitu_block else None,
                                 "stage": "watershed (ws_* kernels): %.1f B/px compulsory, once" % WS_STAGE_BYTES_PER_PIXEL,
                                 "stage_serial_ms_per_step": None if ws_serial_ms is None else round(ws_serial_ms, 3),

@@ -281,7 +281,11 @@ struct CclPlan {
     int *corrupt;  // [B] raised by a fenced walk (see walk_ok): the frame's count comes out as -1
 };
 int ccl_plan(void *workspace, size_t workspace_bytes, int B, int H, int W, CclPlan *plan, const char *who);
+// region_stats != nullptr (W % 4 == 0 and 16-byte aligned label / parent images, else ignored -- the caller then runs the
+// stand-alone table pass): the relabel pass also fills the integer columns of the region table (B, cap, 8) -- rows below
+// counts[b] initialised first, region_sums (B, cap, C) zeroed with them, region_overflow cleared
 int ccl_equal_u8_finish(const uint8_t *in, const CclPlan &plan, bool tile_pass_done, int *labels, int *counts, int B, int H, int W,
-                        hipStream_t s);
+                        hipStream_t s, int region_cap = 0, int region_C = 0, long long *region_stats = nullptr,
+                        double *region_sums = nullptr, int *region_overflow = nullptr);
 
 }  // namespace pcseg
