@@ -78,15 +78,6 @@ int pcseg_median5_u8(const uint8_t *in, uint8_t *out, int B, int H, int W, pcseg
 size_t pcseg_classmap_label_workspace_bytes(int B, int H, int W);
 int pcseg_classmap_label_f32(const float *stack, int C, uint8_t *denoised, int32_t *labels, int32_t *counts,
                              int B, int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
-/* ... + A3: the same call followed by pcseg_region_reduce_sel(labels, counts, denoised, 0, NULL, n_sums, ...), i.e. with
- * the integer columns of the regionprops table (tiff_analysis.py:746-773) and the class at each region's first pixel
- * (:1041-1044) -- but the table is filled BY the pass that writes the final labels (W % 4 == 0, C <= 5: one walk instead
- * of two; other shapes run the two calls).  stats: int64 (B, cap, 8), cls_out: uint8 (B, cap), sums: float64
- * (B, cap, n_sums) zeroed for pcseg_region_sums2 (NULL with n_sums = 0), overflow: int32 (B) or NULL; rows at and beyond
- * counts[b] stay untouched.  Same workspace as pcseg_classmap_label_f32. */
-int pcseg_classmap_label_regions_f32(const float *stack, int C, uint8_t *denoised, int32_t *labels, int32_t *counts,
-                                     int cap, int64_t *stats, uint8_t *cls_out, double *sums, int n_sums, int32_t *overflow,
-                                     int B, int H, int W, void *workspace, size_t workspace_bytes, pcseg_stream_t stream);
 
 /* ---- A2: skimage.measure.label (tiff_analysis.py:743, 260, 829;
  * refine_boundaries.py:64) and scipy.ndimage.label (inside binary_fill_holes).

@@ -28,7 +28,6 @@ SIGNATURES = {
     "pcseg_argmax_planes_f32": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "pcseg_median5_u8": (c_int, [_P, _P, _I, _I, _I, _P]),
     "pcseg_classmap_label_workspace_bytes": (c_size_t, [_I, _I, _I]),
-    "pcseg_classmap_label_regions_f32": (c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_classmap_label_f32": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "pcseg_ccl_workspace_bytes": (c_size_t, [_I, _I, _I]),
     "pcseg_ccl8_equal_u8": (c_int, [_P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),

@@ -13,7 +13,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h", "tile_ops.h", "region_ops.h"]]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h", "tile_ops.h"]]
     deps.append(os.path.join(HERE, "..", "include", "pcseg.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -12,7 +12,6 @@
 #include <type_traits>
 
 #include "common.h"
-#include "region_ops.h"
 #include "tile_ops.h"
 
 namespace pcseg {
@@ -366,19 +365,26 @@ __device__ __forceinline__ void relabel_chains(const int *par, int *lab, const i
         if (val[q] < 0) val[q] = off[q] - val[q];
 }
 
-// the decode of a lane's RELABEL_Q quads: pq[q] = the quad's four parent entries (-1 = none), base[q] = frame index of its
-// first pixel (< 0: no quad); out[q][j] = final labels.  Shared by the streaming pass below and by the pass that builds the
-// region table in the same walk (ccl_relabel_stats_kernel).
 template <typename Pred>
-__device__ __forceinline__ void relabel_quads_decode(const int *par, int *lab, const int *blockoff, const Pred &pred, int b, int64_t n,
-                                                     int nblk, bool chase, int4 (&pq)[RELABEL_Q], const int (&base)[RELABEL_Q],
-                                                     int (&out)[RELABEL_Q][4], int &bad)
+__global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
+                                                                 Pred pred, int64_t n, int nblk, bool chase, int *__restrict__ counts)
 {
-    // the entries themselves are fenced first (common.h, walk_ok): an entry above the index it is stored at -- or past the
-    // frame -- is not a union-find entry; it becomes background and the frame's count -1
+    const int b = blockIdx.y;
+    const int *par = parent + (int64_t)b * n;
+    int *lab = labels + (int64_t)b * n;
+    const int64_t i0 = (int64_t)blockIdx.x * (SCAN_PIX * RELABEL_Q) + threadIdx.x * 4;
+    int4 pq[RELABEL_Q];
 #pragma unroll
     for (int q = 0; q < RELABEL_Q; ++q) {
-        const int i = base[q];
+        const int64_t i = i0 + (int64_t)q * SCAN_PIX;
+        pq[q] = i < n ? *reinterpret_cast<const int4 *>(par + i) : make_int4(-1, -1, -1, -1);
+    }
+    // the entries themselves are fenced first (common.h, walk_ok): an entry above the index it is stored at -- or past the
+    // frame -- is not a union-find entry; it becomes background and the frame's count -1
+    int bad = 0;
+#pragma unroll
+    for (int q = 0; q < RELABEL_Q; ++q) {
+        const int i = (int)(i0 + (int64_t)q * SCAN_PIX);
         if (pq[q].x >= 0 && !walk_ok(i, pq[q].x)) { bad = 1; pq[q].x = -1; }
         if (pq[q].y >= 0 && !walk_ok(i + 1, pq[q].y)) { bad = 1; pq[q].y = -1; }
         if (pq[q].z >= 0 && !walk_ok(i + 2, pq[q].z)) { bad = 1; pq[q].z = -1; }
@@ -422,160 +428,24 @@ __device__ __forceinline__ void relabel_quads_decode(const int *par, int *lab, c
     if (__any(any2)) relabel_chains(par, lab, blockoff, pred, b, n, nblk, chase, root, val2, &bad);
 #pragma unroll
     for (int q = 0; q < RELABEL_Q; ++q) {
+        const int64_t i = i0 + (int64_t)q * SCAN_PIX;
+        if (i >= n) continue;
         const int pv[4] = {pq[q].x, pq[q].y, pq[q].z, pq[q].w};
+        int out[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            out[q][j] = 0;
+            out[j] = 0;
             if (pv[j] < 0) continue;
-            if (pv[j] == lead[q]) out[q][j] = val[q];
-            else if (pv[j] == lead2[q]) out[q][j] = val2[q];
-            else if (third) out[q][j] = relabel_decode(par, lab, blockoff, pred, b, n, nblk, pv[j], chase, &bad);
+            if (pv[j] == lead[q]) out[j] = val[q];
+            else if (pv[j] == lead2[q]) out[j] = val2[q];
+            else if (third) out[j] = relabel_decode(par, lab, blockoff, pred, b, n, nblk, pv[j], chase, &bad);
         }
+        *reinterpret_cast<int4 *>(lab + i) = make_int4(out[0], out[1], out[2], out[3]);
     }
-}
-
-template <typename Pred>
-__global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
-                                                                 Pred pred, int64_t n, int nblk, bool chase, int *__restrict__ counts)
-{
-    const int b = blockIdx.y;
-    const int *par = parent + (int64_t)b * n;
-    int *lab = labels + (int64_t)b * n;
-    const int64_t i0 = (int64_t)blockIdx.x * (SCAN_PIX * RELABEL_Q) + threadIdx.x * 4;
-    int4 pq[RELABEL_Q];
-    int base[RELABEL_Q], out[RELABEL_Q][4];
-#pragma unroll
-    for (int q = 0; q < RELABEL_Q; ++q) {
-        const int64_t i = i0 + (int64_t)q * SCAN_PIX;
-        base[q] = i < n ? (int)i : -1;
-        pq[q] = i < n ? *reinterpret_cast<const int4 *>(par + i) : make_int4(-1, -1, -1, -1);
-    }
-    int bad = 0;
-    relabel_quads_decode(par, lab, blockoff, pred, b, n, nblk, chase, pq, base, out, bad);
-#pragma unroll
-    for (int q = 0; q < RELABEL_Q; ++q)
-        if (base[q] >= 0) *reinterpret_cast<int4 *>(lab + base[q]) = make_int4(out[q][0], out[q][1], out[q][2], out[q][3]);
-    if (bad && counts) counts[b] = -1;
-}
-
-// The relabel pass AND the integer columns of the region table (A3: area, centroid sums, bounding box, first pixel) in one
-// walk (round 4).  The stand-alone table pass (reduce.hip, region_stats_col_kernel) re-read the label image this pass has
-// just written from registers: 64 of its 117 us were that walk.  Here a lane owns 4 adjacent columns and walks DOWN
-// RS_ROWS rows, RELABEL_Q rows at a time (the quads of a batch are the lockstep chains of the pass above; the next batch's
-// parent quads are fetched before the current batch is decoded); the labels it writes feed the vertical-run tracking of the
-// table pass -- parked runs, segmented lane reduction, the block's LDS table, eight lanes per row at the flush -- as they are.
-// The table rows must hold the reduction's neutral element (region_init_launch, after the counts are known).
-constexpr int RS_ROWS = 32;
-static_assert(RS_ROWS % RELABEL_Q == 0 && RS_ROWS <= 64, "whole batches; block-local sums are 32-bit");
-
-template <typename Pred>
-__global__ void __launch_bounds__(256) ccl_relabel_stats_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
-                                                                 Pred pred, int H, int W, int nblk, bool chase, int *__restrict__ counts,
-                                                                 int cap, long long *__restrict__ stats, int *__restrict__ overflow)
-{
-    __shared__ int tags[RED_SLOTS];
-    __shared__ int lstat[RED_SLOTS][8];
-    const TileIndex ti = xcd_tile_index();  // a frame's blocks on one XCD: their table atomics meet in one L2
-    const int b = ti.z;
-    const int64_t n = (int64_t)H * W;
-    const int *par = parent + (int64_t)b * n;
-    int *lab = labels + (int64_t)b * n;
-    long long *gst = stats + (int64_t)b * cap * 8;
-    for (int i = threadIdx.x; i < RED_SLOTS; i += 256) {
-        tags[i] = 0;
-        region_slots_clear(lstat[i], H, W);
-    }
-    __syncthreads();
-    const RegionSlots ls{tags, lstat, nullptr};
-    const int c = (ti.x * 256 + threadIdx.x) * 4;
-    const int r0 = ti.y * RS_ROWS, r1 = min(H, r0 + RS_ROWS);
-    const bool inside = c < W;  // (lanes beyond the frame's width walk zeros: the reductions at the end want all 64 lanes)
-    int cur[4] = {0, 0, 0, 0}, start[4] = {0, 0, 0, 0};
-    int parked_label[4] = {0, 0, 0, 0}, parked_rows[4] = {0, 0, 0, 0};  // first row | end row << 16 (rows < 2^15)
-    int bad = 0;
-    int4 nq[RELABEL_Q];
-    auto fetch = [&](int rb) {
-#pragma unroll
-        for (int q = 0; q < RELABEL_Q; ++q)
-            nq[q] = (inside && rb + q < r1) ? *reinterpret_cast<const int4 *>(par + rowoff(rb + q, W) + c) : make_int4(-1, -1, -1, -1);
-    };
-    fetch(r0);
-    for (int rb = r0; rb < r1; rb += RELABEL_Q) {
-        int4 pq[RELABEL_Q];
-        int base[RELABEL_Q], out[RELABEL_Q][4];
-#pragma unroll
-        for (int q = 0; q < RELABEL_Q; ++q) {
-            pq[q] = nq[q];
-            base[q] = (inside && rb + q < r1) ? (int)rowoff(rb + q, W) + c : -1;
-        }
-        if (rb + RELABEL_Q < r1) fetch(rb + RELABEL_Q);
-        relabel_quads_decode(par, lab, blockoff, pred, b, n, nblk, chase, pq, base, out, bad);
-#pragma unroll
-        for (int q = 0; q < RELABEL_Q; ++q) {
-            if (base[q] >= 0) *reinterpret_cast<int4 *>(lab + base[q]) = make_int4(out[q][0], out[q][1], out[q][2], out[q][3]);
-            const int r = rb + q;
-            if (r >= r1) continue;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int l = out[q][j];  // (0 outside the frame's width and for background)
-                if (l != cur[j]) {
-                    if (cur[j] > 0) {
-                        // (a column seldom ends two runs inside one block)
-                        if (parked_label[j])
-                            run_commit(ls, gst, overflow, b, cap,
-                                       run_sum(parked_label[j], parked_rows[j] & 0xFFFF, parked_rows[j] >> 16, c + j, W));
-                        parked_label[j] = cur[j];
-                        parked_rows[j] = start[j] | (r << 16);
-                    }
-                    cur[j] = l;
-                    start[j] = r;
-                }
-            }
-        }
-    }
-    // end of the block: the open runs and the parked ones, each folded over the lane's four columns first (they usually sit
-    // in the same region), then over the lanes (region_stats_col_kernel)
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        RunSum q[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            q[j] = pass == 0 ? run_sum(cur[j], start[j], r1, c + j, W)
-                             : run_sum(parked_label[j], parked_rows[j] & 0xFFFF, parked_rows[j] >> 16, c + j, W);
-#pragma unroll
-        for (int j = 1; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < j; ++i)
-                if (q[j].label > 0 && q[j].label == q[i].label) {
-                    run_merge(q[i], q[j]);
-                    q[j].label = 0;
-                }
-#pragma unroll
-        for (int j = 1; j < 4; ++j)
-            if (q[0].label <= 0 && q[j].label > 0) {
-                q[0] = q[j];
-                q[j].label = 0;
-            }
-        if (q[0].label < 0) q[0].label = 0;
-        wave_commit(ls, gst, overflow, b, cap, q[0]);
-#pragma unroll
-        for (int j = 1; j < 4; ++j)
-            if (q[j].label > 0) run_commit(ls, gst, overflow, b, cap, q[j]);
-    }
-    __syncthreads();
-    region_slots_flush8(tags, lstat, gst);
     if (bad && counts) counts[b] = -1;
 }
 
 // ---- host-side drivers ---------------------------------------------------
-// region table to be filled by the relabel pass (W % 4 == 0, 16-byte aligned images; checked by the caller)
-struct CclRegionOut {
-    int cap, C;
-    long long *stats;  // (B, cap, 8)
-    double *sums;      // (B, cap, C) zeroed for the rows below counts[b], or nullptr
-    int *overflow;     // (B), may be nullptr
-};
-
 struct CclWs {
     int *parent;
     int *blockcount;
@@ -623,7 +493,7 @@ static int ccl_roots(KeyFn keyfn, int *parent, int B, int H, int W, hipStream_t 
 // parent must hold roots that are NOT yet flattened when flatten == true
 template <typename Pred>
 static int ccl_compact(int *parent, int *blockcount, int nblk, int *labels, int *counts, Pred pred, bool flatten,
-                       int B, int H, int W, hipStream_t s, int *corrupt = nullptr, const CclRegionOut *region = nullptr)
+                       int B, int H, int W, hipStream_t s, int *corrupt = nullptr)
 {
     int64_t n = (int64_t)H * W;
     dim3 grid(nblk, B);
@@ -633,16 +503,7 @@ static int ccl_compact(int *parent, int *blockcount, int nblk, int *labels, int 
     PCSEG_CHECK_LAUNCH();
     PCSEG_LAUNCH(ccl_scan_blocks_kernel, dim3(B), dim3(256), 0, s, blockcount, counts, nblk, (const int *)corrupt);
     PCSEG_CHECK_LAUNCH();
-    if (region && region->stats) {
-        // the region table's integer columns in the same walk as the final labels (ccl_relabel_stats_kernel); its rows
-        // start from the reduction's neutral element, the first counts[b] of them (known since the scan above)
-        if (region->overflow) PCSEG_CHECK_HIP(hipMemsetAsync(region->overflow, 0, sizeof(int) * (size_t)B, s));
-        int rc = region_init_launch(counts, region->cap, region->C, B, H, W, region->stats, region->sums, s);
-        if (rc) return rc;
-        const dim3 sgrid((W / 4 + 255) / 256, (H + RS_ROWS - 1) / RS_ROWS, B);
-        PCSEG_LAUNCH((ccl_relabel_stats_kernel<Pred>), sgrid, dim3(256), 0, s, (const int *)parent, labels, (const int *)blockcount, pred, H,
-                     W, nblk, flatten, counts, region->cap, region->stats, region->overflow);
-    } else if ((n & 3) == 0 && (((uintptr_t)parent | (uintptr_t)labels) & 15) == 0) {
+    if ((n & 3) == 0 && (((uintptr_t)parent | (uintptr_t)labels) & 15) == 0) {
         const dim3 qgrid((unsigned)((n + SCAN_PIX * RELABEL_Q - 1) / (SCAN_PIX * RELABEL_Q)), B);
         PCSEG_LAUNCH((ccl_relabel_quads_kernel<Pred>), qgrid, dim3(256), 0, s, (const int *)parent, labels, (const int *)blockcount, pred, n,
                      nblk, flatten, counts);
@@ -685,7 +546,7 @@ int ccl_plan(void *workspace, size_t workspace_bytes, int B, int H, int W, CclPl
 }
 
 int ccl_equal_u8_finish(const uint8_t *in, const CclPlan &plan, bool tile_pass_done, int *labels, int *counts, int B, int H, int W,
-                        hipStream_t s, int region_cap, int region_C, long long *region_stats, double *region_sums, int *region_overflow)
+                        hipStream_t s)
 {
     const KeyEqU8 keyfn{in, W, (int64_t)H * W};
     PCSEG_CHECK_HIP(hipMemsetAsync(plan.corrupt, 0, sizeof(int) * (size_t)B, s));
@@ -700,10 +561,7 @@ int ccl_equal_u8_finish(const uint8_t *in, const CclPlan &plan, bool tile_pass_d
         PCSEG_LAUNCH((ccl_border_kernel<KeyEqU8, true>), bgrid, dim3(256), 0, s, keyfn, plan.parent, H, W, plan.corrupt);
         PCSEG_CHECK_LAUNCH();
     }
-    const CclRegionOut region{region_cap, region_C, region_stats, region_sums, region_overflow};
-    const bool fused = region_stats && (W & 3) == 0 && (((uintptr_t)plan.parent | (uintptr_t)labels) & 15) == 0;
-    return ccl_compact(plan.parent, plan.blockcount, plan.nblk, labels, counts, PredAll(), true, B, H, W, s, plan.corrupt,
-                       fused ? &region : nullptr);
+    return ccl_compact(plan.parent, plan.blockcount, plan.nblk, labels, counts, PredAll(), true, B, H, W, s, plan.corrupt);
 }
 
 // ---- roots(+1) image -> parent(-1 bg) conversion for pcseg_compact_labels

@@ -192,6 +192,30 @@ __device__ __forceinline__ void unite_lds_pair(int *par, int a, int b)
     }
 }
 
+// with path halving (long chains: the lake components of the watershed's second level wind through a tile)
+__device__ __forceinline__ int find_lds_halving(int *par, int x)
+{
+    int p;
+    while ((p = ld_lds(par + x)) != x) {
+        const int g = ld_lds(par + p);
+        if (g != p) st_lds(par + x, g);  // re-pointing x at its grandparent keeps it in its set (parents only ever decrease)
+        x = g;
+    }
+    return x;
+}
+__device__ __forceinline__ void unite_lds_halving(int *par, int a, int b)
+{
+    for (;;) {
+        a = find_lds_halving(par, a);
+        b = find_lds_halving(par, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        const int old = atomicMin(&par[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
 // ---- global union-find (parents only ever decrease; stale reads cost iterations, never correctness)
 //
 // WALKS ARE FENCED.  In a well-formed union-find image the entry stored at index x is a smaller-or-equal index of the same
@@ -281,11 +305,7 @@ struct CclPlan {
     int *corrupt;  // [B] raised by a fenced walk (see walk_ok): the frame's count comes out as -1
 };
 int ccl_plan(void *workspace, size_t workspace_bytes, int B, int H, int W, CclPlan *plan, const char *who);
-// region_stats != nullptr (W % 4 == 0 and 16-byte aligned label / parent images, else ignored -- the caller then runs the
-// stand-alone table pass): the relabel pass also fills the integer columns of the region table (B, cap, 8) -- rows below
-// counts[b] initialised first, region_sums (B, cap, C) zeroed with them, region_overflow cleared
 int ccl_equal_u8_finish(const uint8_t *in, const CclPlan &plan, bool tile_pass_done, int *labels, int *counts, int B, int H, int W,
-                        hipStream_t s, int region_cap = 0, int region_C = 0, long long *region_stats = nullptr,
-                        double *region_sums = nullptr, int *region_overflow = nullptr);
+                        hipStream_t s);
 
 }  // namespace pcseg

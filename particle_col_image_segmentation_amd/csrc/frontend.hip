@@ -6,7 +6,6 @@
 // halo), the denoised map and the union-find image written once -- instead of planes -> class map -> denoised map ->
 // union-find image through three launches.
 #include "common.h"
-#include "region_ops.h"
 #include "tile_ops.h"
 
 namespace pcseg {
@@ -170,46 +169,6 @@ int pcseg_classmap_label_f32(const float *stack, int C, uint8_t *denoised, int32
         PCSEG_LAUNCH(classmap_median_ccl_kernel<0>, grid, dim3(256), 0, s, stack, C, denoised, plan.parent, H, W);
     PCSEG_CHECK_LAUNCH();
     return ccl_equal_u8_finish(denoised, plan, true, labels, counts, B, H, W, s);
-}
-
-int pcseg_classmap_label_regions_f32(const float *stack, int C, uint8_t *denoised, int32_t *labels, int32_t *counts, int cap,
-                                     int64_t *stats, uint8_t *cls_out, double *sums, int n_sums, int32_t *overflow, int B, int H, int W,
-                                     void *workspace, size_t workspace_bytes, pcseg_stream_t stream)
-{
-    PCSEG_REQUIRE(stack && denoised && labels && counts && stats && cls_out && workspace && cap >= 1 && C >= 1 && C <= 255 &&
-                      n_sums >= 0 && n_sums <= 8 && (n_sums == 0 || sums) && check_shape(B, H, W),
-                  "bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    const size_t ccl_bytes = pcseg_ccl_workspace_bytes(B, H, W);
-    PCSEG_REQUIRE(workspace_bytes >= ccl_bytes + align_up((size_t)B * H * W), "workspace too small");
-    CclPlan plan;
-    int rc = ccl_plan(workspace, ccl_bytes, B, H, W, &plan, "classmap_label_regions");
-    if (rc) return rc;
-#ifndef PCSEG_NO_FUSED_STATS
-#define PCSEG_NO_FUSED_STATS 0  // A/B builds: 1 = always the two separate passes
-#endif
-    const bool fused = !PCSEG_NO_FUSED_STATS && C <= 5 && (W & 3) == 0 && (((uintptr_t)plan.parent | (uintptr_t)labels) & 15) == 0;
-    if (!fused) {
-        // ragged widths / unaligned images / more than five planes: the two calls this one stands for
-        rc = pcseg_classmap_label_f32(stack, C, denoised, labels, counts, B, H, W, workspace, workspace_bytes, stream);
-        if (rc) return rc;
-        return pcseg_region_reduce_sel(labels, counts, denoised, 0, nullptr, n_sums, B, H, W, cap, stats, cls_out, n_sums ? sums : nullptr,
-                                       overflow, stream);
-    }
-    const dim3 grid((W + MED_TW - 1) / MED_TW, (H + MED_TH - 1) / MED_TH, B);
-    if (C == 5)
-        PCSEG_LAUNCH(classmap_median_ccl_kernel<5>, grid, dim3(256), 0, s, stack, C, denoised, plan.parent, H, W);
-    else if (C == 4)
-        PCSEG_LAUNCH(classmap_median_ccl_kernel<4>, grid, dim3(256), 0, s, stack, C, denoised, plan.parent, H, W);
-    else if (C == 3)
-        PCSEG_LAUNCH(classmap_median_ccl_kernel<3>, grid, dim3(256), 0, s, stack, C, denoised, plan.parent, H, W);
-    else
-        PCSEG_LAUNCH(classmap_median_ccl_kernel<0>, grid, dim3(256), 0, s, stack, C, denoised, plan.parent, H, W);
-    PCSEG_CHECK_LAUNCH();
-    // the relabel pass fills the table's integer columns in the same walk (ccl.hip, ccl_relabel_stats_kernel)
-    rc = ccl_equal_u8_finish(denoised, plan, true, labels, counts, B, H, W, s, cap, n_sums, (long long *)stats, n_sums ? sums : nullptr, overflow);
-    if (rc) return rc;
-    return region_class_launch((const long long *)stats, denoised, counts, cls_out, cap, B, H, W, s);
 }
 
 }  // extern "C"

@@ -76,26 +76,6 @@ __device__ __forceinline__ void ws_load_tile(T *s, const T *__restrict__ g, int 
 // monotone (min / 0->label), so concurrent sweeps may read each other's half-finished values: a stale read only
 // costs another outer iteration.  One sweep carries information across the whole tile, so the number of outer
 // iterations is the number of direction changes of the dependency paths, not their length.
-// LDS cell of the relaxation: (level, value) as one 64-bit word.  PCSEG_WS_MIN64 (A/B, round 4) puts the LEVEL IN THE HIGH
-// dword: the cell as a 64-bit integer is then ordered by its level (the value half never changes), and the sweep's atomic can
-// be ONE ds_min_u64 on the whole cell -- banked like ds_read_b64 over 64 dwords, where the lanes of a wavefront sweep (an even
-// number of dwords apart, 8-byte cells) never collide -- instead of a ds_min_u32 on the level dword, which the 32-dword
-// banking of 4-byte operations serves 2-way conflicted (46 % of this kernel's LDS cycles, profiles/r03_pmc_sq_summary.txt).
-#ifndef PCSEG_WS_MIN64
-#define PCSEG_WS_MIN64 0
-#endif
-#if PCSEG_WS_MIN64
-#define WS_CELL(level, value) make_uint2((value), (level))
-#define WS_LEVEL(cell) ((cell).y)
-#define WS_VALUE(cell) ((cell).x)
-constexpr int WS_LW = 1;  // dword of the level inside a cell
-#else
-#define WS_CELL(level, value) make_uint2((level), (value))
-#define WS_LEVEL(cell) ((cell).x)
-#define WS_VALUE(cell) ((cell).y)
-constexpr int WS_LW = 0;
-#endif
-
 struct SweepLine {
     int start, step;  // LDS index of the halo element in front of the line, and the index step along the line
 };
@@ -113,7 +93,7 @@ __device__ __forceinline__ SweepLine ws_line()
 template <typename T>
 __device__ __forceinline__ void ws_store_tile(const T *s, T *__restrict__ g, int r0, int c0, int H, int W)
 {
-    for (int i = threadIdx.x; i < WS_T * WS_T; i += 256) {
+    for (int i = threadIdx.x; i < WS_T * WS_T; i += blockDim.x) {
         int lr = i / WS_T, lc = i % WS_T;
         int r = r0 + lr, c = c0 + lc;
         if (r < H && c < W) g[rowoff(r, W) + c] = s[(lr + 1) * WS_P + lc + 1];
@@ -126,6 +106,7 @@ template <typename T>
 __device__ __forceinline__ void ws_mark_changed_edges(const T *s, const T *__restrict__ g, uint8_t *dirty_out,
                                                       int b, int tx, int ty, int tilesX, int tilesY, int r0, int c0, int H, int W)
 {
+    if (threadIdx.x >= 256) return;  // (wave e = edge e: the first four waves of a wider block)
     const int e = threadIdx.x >> 6, j = threadIdx.x & 63;
     const int lr = e == 0 ? 1 : (e == 1 ? WS_T : j + 1);
     const int lc = e == 2 ? 1 : (e == 3 ? WS_T : j + 1);
@@ -195,7 +176,7 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
 {
     unsigned *sLw = reinterpret_cast<unsigned *>(sLV);  // the L half of element i is word 2 * i
     unsigned diff = 0;  // != 0 once a cell of this line was lowered
-    unsigned prev = WS_LEVEL(sLV[start]);
+    unsigned prev = sLV[start].x;
     int base = start + STEP;
 #pragma unroll 1
     for (int k0 = 0; k0 < 64; k0 += WS_BATCH, base += WS_BATCH * STEP) {
@@ -241,7 +222,7 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
             // value <= L holds for every cell (seeds start at their value, everything else at +inf, and a level never
             // drops below its cell's value), so min(L, max(value, prev)) is the MEDIAN of the three: one v_med3_u32 on
             // the serial chain instead of v_max followed by v_min
-            const unsigned cur = WS_LEVEL(lv[j]), v = WS_VALUE(lv[j]);
+            const unsigned cur = lv[j].x, v = lv[j].y;
             nw[j] = min(max(v, prev), max(min(v, prev), cur));
             batch_diff |= cur ^ nw[j];
             prev = nw[j];
@@ -251,7 +232,7 @@ __device__ __forceinline__ bool ws_sweep(uint2 *sLV, int start)
             // word measured 13 % slower, a compare + masked store 10 %), and still monotone when another wave lowered
             // the cell since the batch was read
 #pragma unroll
-            for (int j = 0; j < WS_BATCH; ++j) atomicMin(&sLw[2 * (base + j * STEP) + WS_LW], nw[j]);
+            for (int j = 0; j < WS_BATCH; ++j) atomicMin(&sLw[2 * (base + j * STEP)], nw[j]);
             diff |= batch_diff;
         }
     }
@@ -291,20 +272,20 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
     {   // the first row takes the halo row's levels before the sweep (lane = column): lane 0 then needs no `up`
         constexpr int fr = DR > 0 ? 1 : WS_T, hr = DR > 0 ? 0 : WS_T + 1;
         const uint2 c = sLV[fr * P + 1 + lane];
-        const unsigned h = WS_LEVEL(sLV[hr * P + 1 + lane]);
-        const unsigned nw = min(WS_LEVEL(c), max(WS_VALUE(c), h));
-        atomicMin(&sLw[2 * (fr * P + 1 + lane) + WS_LW], nw);
-        diff |= __ballot(nw != WS_LEVEL(c));
+        const unsigned h = sLV[hr * P + 1 + lane].x;
+        const unsigned nw = min(c.x, max(c.y, h));
+        atomicMin(&sLw[2 * (fr * P + 1 + lane)], nw);
+        diff |= __ballot(nw != c.x);
     }
     const int lr = DR > 0 ? lane + 1 : WS_T - lane;  // the lane's row (LDS coordinates 1 .. 64)
     const uint2 *row = sLV + lr * P;
-    const unsigned halo = WS_LEVEL(row[DC > 0 ? 0 : WS_T + 1]);
+    const unsigned halo = row[DC > 0 ? 0 : WS_T + 1].x;
     const int u0 = (0 - lane) & 63;                   // cyclic position at step 0
     // what the first step finds behind it: the row's cell at position u0 - 1 as it is now
-    unsigned left = WS_LEVEL(row[DC > 0 ? u0 : WS_T + 1 - u0]);  // (u0 == 0: replaced by the halo cell at the first step anyway)
+    unsigned left = row[DC > 0 ? u0 : WS_T + 1 - u0].x;  // (u0 == 0: replaced by the halo cell at the first step anyway)
     // what the next lane finds above its first cell: this row's cell at THAT lane's first position
     const int un = (0 - (lane + 1)) & 63;
-    unsigned prev = WS_LEVEL(row[DC > 0 ? 1 + un : WS_T - un]);
+    unsigned prev = row[DC > 0 ? 1 + un : WS_T - un].x;
     // byte address of the row's cell at cyclic position 0, and the step per position
     const unsigned a0 = (unsigned)(uintptr_t)(row + (DC > 0 ? 1 : WS_T));
 #pragma unroll 1
@@ -342,11 +323,10 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
             const unsigned long long at0 = (1ull << k) << j0;  // the lane that is at position 0 now restarts from its halo cell
             unsigned lf;
             asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lf) : "v"(left), "v"(halo), "s"(at0));
-            const unsigned cur = PCSEG_WS_MIN64 ? t[k].y : t[k].x, v = PCSEG_WS_MIN64 ? t[k].x : t[k].y;
+            const unsigned cur = t[k].x, v = t[k].y;
             const unsigned m = min(up, lf);
             const unsigned cand = min(max(v, m), max(min(v, m), cur));  // median(value, m, cur) = min(cur, max(value, m))
             wr[k] = cand;
-            if (PCSEG_WS_MIN64) t[k].y = cand;  // the cell as it should be: (value, lowered level), the 64-bit atomic's operand
 #if PCSEG_WS_SWEEP_MASKS == 0
             lane_diff |= cur ^ cand;
             lowered[k] = true;
@@ -364,133 +344,15 @@ __device__ __forceinline__ bool ws_quadrant_sweep(uint2 *sLV, int lane)
             // unconditional LDS atomic min per cell of a changed batch (variant 2 predicates it per lane: measured slower);
             // still monotone when another wave lowered the cell since the batch was read.  (The level is the first word of
             // the cell: the read's address and offset serve the atomic as they are.)
-#if PCSEG_WS_MIN64
-#define PCSEG_DS_MIN(k)                                                                                                             \
-            if (PCSEG_WS_SWEEP_MASKS < 2 || lowered[k])                                                                                 \
-                asm volatile("ds_min_u64 %0, %1 offset:%2" : : "v"(ba[k]), "v"(t[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
-#else
 #define PCSEG_DS_MIN(k)                                                                                                             \
             if (PCSEG_WS_SWEEP_MASKS < 2 || lowered[k])                                                                                 \
                 asm volatile("ds_min_u32 %0, %1 offset:%2" : : "v"(ba[k]), "v"(wr[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
-#endif
             PCSEG_DS_MIN(0) PCSEG_DS_MIN(1) PCSEG_DS_MIN(2) PCSEG_DS_MIN(3)
             PCSEG_DS_MIN(4) PCSEG_DS_MIN(5) PCSEG_DS_MIN(6) PCSEG_DS_MIN(7)
 #undef PCSEG_DS_MIN
             diff |= batch_diff;
         }
     }
-    return diff != 0;
-}
-
-// The same sweep with the LDS reads of batch j + 1 in flight while batch j is computed (PCSEG_WS_PIPE, round 4).  The plain
-// form issues its eight reads and waits for all of them before the first of its ~50 vector instructions, eight times a
-// sweep; with four waves per SIMD all doing the same, neither the LDS (56 % busy) nor the VALU (17 %) was saturated
-// (profiles/r03_pmc_sq_summary.txt: 38 % of the wave cycles waiting, 26 % issue-stalled).  The loop is unrolled by two so that
-// the two register sets swap roles without moves.  A batch's cells are read BEFORE the previous batch's atomics are
-// issued: they are other cells of the lane's own row (nothing this wave writes in between), and what another wave lowers
-// meanwhile is picked up an iteration later, which the monotone update tolerates -- as everywhere in these sweeps.
-// LDS operations return in order: behind [reads of the next batch][atomics of this batch] `lgkmcnt(8)` says the reads are
-// there; without atomics it has to be `lgkmcnt(0)`.
-#ifndef PCSEG_WS_PIPE
-#define PCSEG_WS_PIPE 0
-#endif
-template <int DR, int DC, int P>
-__device__ __forceinline__ bool ws_quadrant_sweep_pipe(uint2 *sLV, int lane)
-{
-    unsigned *sLw = reinterpret_cast<unsigned *>(sLV);
-    typedef unsigned u2v __attribute__((ext_vector_type(2)));
-    unsigned long long diff = 0;
-    const int lr = DR > 0 ? lane + 1 : WS_T - lane;  // the lane's row (LDS coordinates 1 .. 64)
-    const uint2 *row = sLV + lr * P;
-    const int u0 = (0 - lane) & 63;                   // cyclic position at step 0
-    const unsigned a0 = (unsigned)(uintptr_t)(row + (DC > 0 ? 1 : WS_T));
-    unsigned baA[8], baB[8];
-    u2v tA[8], tB[8];
-#define PCSEG_ISSUE(BA, T, J0)                                                                                                 \
-    {                                                                                                                          \
-        const int ub_ = (u0 + (J0)) & 63;                                                                                      \
-        const unsigned base_a_ = DC > 0 ? a0 + 8u * (unsigned)ub_ : a0 - 8u * (unsigned)ub_ - 56u;                             \
-        const unsigned base_b_ = DC > 0 ? base_a_ - 512u : base_a_ + 512u;                                                     \
-        PCSEG_ISSUE1(BA, T, J0, 0) PCSEG_ISSUE1(BA, T, J0, 1) PCSEG_ISSUE1(BA, T, J0, 2) PCSEG_ISSUE1(BA, T, J0, 3)            \
-        PCSEG_ISSUE1(BA, T, J0, 4) PCSEG_ISSUE1(BA, T, J0, 5) PCSEG_ISSUE1(BA, T, J0, 6) PCSEG_ISSUE1(BA, T, J0, 7)            \
-        __builtin_amdgcn_sched_barrier(0); /* all eight reads go out BEFORE the batch that is computed under them */           \
-    }
-#define PCSEG_ISSUE1(BA, T, J0, k)                                                                                             \
-        {                                                                                                                      \
-            const unsigned long long wrapped_ = (((1ull << (k)) - 1ull) << 1) << (J0);  /* lanes J0 + 1 .. J0 + k */           \
-            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(BA[k]) : "v"(base_a_), "v"(base_b_), "s"(wrapped_));                  \
-            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(T[k]) : "v"(BA[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))));     \
-        }
-    // batch 0's reads go out first; the halo-row step below (its own read, atomic and wait) runs under them
-    PCSEG_ISSUE(baA, tA, 0)
-    {   // the first row takes the halo row's levels before the sweep (lane = column): lane 0 then needs no `up`
-        constexpr int fr = DR > 0 ? 1 : WS_T, hr = DR > 0 ? 0 : WS_T + 1;
-        const uint2 c = sLV[fr * P + 1 + lane];
-        const unsigned h = WS_LEVEL(sLV[hr * P + 1 + lane]);
-        const unsigned nw = min(WS_LEVEL(c), max(WS_VALUE(c), h));
-        atomicMin(&sLw[2 * (fr * P + 1 + lane) + WS_LW], nw);
-        diff |= __ballot(nw != WS_LEVEL(c));
-    }
-    const unsigned halo = WS_LEVEL(row[DC > 0 ? 0 : WS_T + 1]);
-    unsigned left = WS_LEVEL(row[DC > 0 ? u0 : WS_T + 1 - u0]);
-    const int un = (0 - (lane + 1)) & 63;
-    unsigned prev = WS_LEVEL(row[DC > 0 ? 1 + un : WS_T - un]);
-    // the three reads above are "used" HERE: the compiler's wait for them then sits in front of the loop.  Left to the first
-    // real use -- inside the loop -- it becomes an s_waitcnt lgkmcnt(0) at the loop head (the wait-count pass cannot count
-    // across the back edge), i.e. a drain of the reads this loop keeps in flight, once per iteration
-    asm volatile("" : "+v"(left), "+v"(prev) : "v"(halo));
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tA[0]), "+v"(tA[1]), "+v"(tA[2]), "+v"(tA[3]), "+v"(tA[4]), "+v"(tA[5]), "+v"(tA[6]), "+v"(tA[7]));
-    // (lane 0 of a row-0 wave re-reads the cell the halo-row step has just lowered one batch late at worst: monotone)
-#define PCSEG_COMPUTE(BA, T, TN, J0, HAVE_NEXT)                                                                                \
-    {                                                                                                                          \
-        unsigned wr_[8];                                                                                                       \
-        unsigned long long batch_diff_ = 0;                                                                                    \
-        _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                                        \
-            const unsigned up_ = (unsigned)__builtin_amdgcn_update_dpp((int)WS_INF, (int)prev, 0x138, 0xF, 0xF, false);        \
-            const unsigned long long at0_ = (1ull << k) << (J0);                                                               \
-            unsigned lf_;                                                                                                      \
-            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lf_) : "v"(left), "v"(halo), "s"(at0_));                              \
-            const unsigned cur_ = PCSEG_WS_MIN64 ? T[k].y : T[k].x, v_ = PCSEG_WS_MIN64 ? T[k].x : T[k].y;                     \
-            const unsigned m_ = min(up_, lf_);                                                                                 \
-            const unsigned cand_ = min(max(v_, m_), max(min(v_, m_), cur_));                                                   \
-            wr_[k] = cand_;                                                                                                    \
-            if (PCSEG_WS_MIN64) T[k].y = cand_;                                                                                \
-            batch_diff_ |= __ballot(cur_ != cand_);                                                                            \
-            left = cand_;                                                                                                      \
-            prev = cand_;                                                                                                      \
-        }                                                                                                                      \
-        if (batch_diff_ != 0) {                                                                                                \
-            PCSEG_PMIN(BA, T, wr_, 0) PCSEG_PMIN(BA, T, wr_, 1) PCSEG_PMIN(BA, T, wr_, 2) PCSEG_PMIN(BA, T, wr_, 3)            \
-            PCSEG_PMIN(BA, T, wr_, 4) PCSEG_PMIN(BA, T, wr_, 5) PCSEG_PMIN(BA, T, wr_, 6) PCSEG_PMIN(BA, T, wr_, 7)            \
-            diff |= batch_diff_;                                                                                               \
-            if (HAVE_NEXT)                                                                                                     \
-                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(TN[0]), "+v"(TN[1]), "+v"(TN[2]), "+v"(TN[3]), "+v"(TN[4]), "+v"(TN[5]), "+v"(TN[6]), "+v"(TN[7])); \
-        } else if (HAVE_NEXT) {                                                                                                \
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(TN[0]), "+v"(TN[1]), "+v"(TN[2]), "+v"(TN[3]), "+v"(TN[4]), "+v"(TN[5]), "+v"(TN[6]), "+v"(TN[7])); \
-        }                                                                                                                      \
-    }
-#if PCSEG_WS_MIN64
-#define PCSEG_PMIN(BA, T, WR, k) \
-            asm volatile("ds_min_u64 %0, %1 offset:%2" : : "v"(BA[k]), "v"(T[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
-#else
-#define PCSEG_PMIN(BA, T, WR, k) \
-            asm volatile("ds_min_u32 %0, %1 offset:%2" : : "v"(BA[k]), "v"(WR[k]), "n"(DC > 0 ? 8 * (k) : 8 * (7 - (k))) : "memory");
-#endif
-#pragma unroll 1
-    for (int j0 = 0; j0 < WS_T; j0 += 16) {
-        PCSEG_ISSUE(baB, tB, j0 + 8)
-        PCSEG_COMPUTE(baA, tA, tB, j0, true)
-        if (j0 + 16 < WS_T) {
-            PCSEG_ISSUE(baA, tA, j0 + 16)
-            PCSEG_COMPUTE(baB, tB, tA, j0 + 8, true)
-        } else {
-            PCSEG_COMPUTE(baB, tB, tA, j0 + 8, false)
-        }
-    }
-#undef PCSEG_ISSUE
-#undef PCSEG_ISSUE1
-#undef PCSEG_COMPUTE
-#undef PCSEG_PMIN
     return diff != 0;
 }
 
@@ -546,9 +408,9 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
     // (L, value) of a pixel before any relaxation
     auto initial = [&](int r, int c) -> uint2 {
         const int64_t g = fbase + rowoff(r, W) + c;
-        if (!in.mask[g]) return WS_CELL(WS_INF, WS_INF);
+        if (!in.mask[g]) return make_uint2(WS_INF, WS_INF);
         const unsigned v = ws_key(in.img[(int64_t)b * in.frame_stride + rowoff(r, W) + c]);
-        return WS_CELL(in.markers[g] != 0 ? v : WS_INF, v);
+        return make_uint2(in.markers[g] != 0 ? v : WS_INF, v);
     };
     if (in.vec) {
         // The tile load is ONE batch of loads per thread, not a loop of dependent round trips: every access goes to a
@@ -596,7 +458,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
                         const bool msk = inside && ((k4[t] >> (8 * j)) & 255u) != 0;
                         key[j] = msk ? ws_key(fv[j]) : WS_INF;
                         lab[j] = msk ? mv[j] : 0;
-                        sLV[lr * P + 1 + 4 * q + j] = WS_CELL(lab[j] != 0 ? key[j] : WS_INF, key[j]);
+                        sLV[lr * P + 1 + 4 * q + j] = make_uint2(lab[j] != 0 ? key[j] : WS_INF, key[j]);
                     }
                     if (inside && lr >= 1 && lr <= T) {  // own pixels: publish value keys and seed labels
                         const int64_t g = fbase + rowoff(r, W) + c;
@@ -608,7 +470,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             if (halo_thread) {
                 const bool msk = h_in && hk != 0;
                 const unsigned key = msk ? ws_key(hf) : WS_INF;
-                sLV[h_lr * P + h_lc] = WS_CELL(msk && hm != 0 ? key : WS_INF, key);
+                sLV[h_lr * P + h_lc] = make_uint2(msk && hm != 0 ? key : WS_INF, key);
             }
         } else {
             uint4 l4[TRIPS], v4[TRIPS];
@@ -629,29 +491,30 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
                     const int r = r0 + lr - 1, c = c0 + 4 * q;
                     const bool inside = r >= 0 && r < H && c >= 0 && c < W;
                     uint2 *dst = sLV + lr * P + 1 + 4 * q;
-                    dst[0] = inside ? WS_CELL(l4[t].x, v4[t].x) : WS_CELL(WS_INF, WS_INF);
-                    dst[1] = inside ? WS_CELL(l4[t].y, v4[t].y) : WS_CELL(WS_INF, WS_INF);
-                    dst[2] = inside ? WS_CELL(l4[t].z, v4[t].z) : WS_CELL(WS_INF, WS_INF);
-                    dst[3] = inside ? WS_CELL(l4[t].w, v4[t].w) : WS_CELL(WS_INF, WS_INF);
+                    dst[0] = inside ? make_uint2(l4[t].x, v4[t].x) : make_uint2(WS_INF, WS_INF);
+                    dst[1] = inside ? make_uint2(l4[t].y, v4[t].y) : make_uint2(WS_INF, WS_INF);
+                    dst[2] = inside ? make_uint2(l4[t].z, v4[t].z) : make_uint2(WS_INF, WS_INF);
+                    dst[3] = inside ? make_uint2(l4[t].w, v4[t].w) : make_uint2(WS_INF, WS_INF);
                 }
             }
-            if (halo_thread) sLV[h_lr * P + h_lc] = h_in ? WS_CELL(hl, hv) : WS_CELL(WS_INF, WS_INF);
+            if (halo_thread) sLV[h_lr * P + h_lc] = h_in ? make_uint2(hl, hv) : make_uint2(WS_INF, WS_INF);
         }
     } else
     for (int i = tid; i < S * S; i += NT) {
         int lr = i / S, lc = i % S;
         int r = r0 + lr - 1, c = c0 + lc - 1;
-        uint2 lv = WS_CELL(WS_INF, WS_INF);
+        uint2 lv = make_uint2(WS_INF, WS_INF);
         if (r >= 0 && r < H && c >= 0 && c < W) {
             if (FIRST) {
                 lv = initial(r, c);
                 if (lr >= 1 && lr <= T && lc >= 1 && lc <= T) {  // own pixels: publish value key and seed label
                     const int64_t g = fbase + rowoff(r, W) + c;
-                    val[g] = WS_VALUE(lv);
-                    in.out[g] = WS_VALUE(lv) != WS_INF ? in.markers[g] : 0;
+                    val[g] = lv.y;
+                    in.out[g] = lv.y != WS_INF ? in.markers[g] : 0;
                 }
             } else {
-                lv = WS_CELL(L[fbase + rowoff(r, W) + c], val[fbase + rowoff(r, W) + c]);
+                lv.x = L[fbase + rowoff(r, W) + c];
+                lv.y = val[fbase + rowoff(r, W) + c];
             }
         }
         sLV[lr * P + lc] = lv;
@@ -665,7 +528,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
     const int qy = e < 4 ? (e >> 1) : (e & 1), qx = e < 4 ? (e & 1) : ((e >> 1) & 1);
     const int rim_lr = e < 4 ? (qy ? T : 1) : qy * G::HE + ej + 1;
     const int rim_lc = e < 4 ? qx * G::HE + ej + 1 : (qx ? T : 1);
-    const unsigned rim_before = rim_thread ? WS_LEVEL(sLV[rim_lr * P + rim_lc]) : 0u;
+    const unsigned rim_before = rim_thread ? sLV[rim_lr * P + rim_lc].x : 0u;
     // wave = (direction, group of 64 lines, 64-cell segment of the lines): the segments of a line are swept at the same
     // time, each starting from the cell in front of it -- its neighbour segment's last cell, or the halo
     const int wave = tid >> 6, lane = tid & 63;
@@ -679,12 +542,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
         // one code path per direction: the step is a compile-time constant there, so the LDS addresses of a batch are
         // base + constant
         bool changed;
-        if constexpr (PCSEG_WS_FSM && T == 64 && PCSEG_WS_PIPE) {
-            if (dir == 0) changed = ws_quadrant_sweep_pipe<1, 1, P>(sLV, lane);
-            else if (dir == 1) changed = ws_quadrant_sweep_pipe<1, -1, P>(sLV, lane);
-            else if (dir == 2) changed = ws_quadrant_sweep_pipe<-1, 1, P>(sLV, lane);
-            else changed = ws_quadrant_sweep_pipe<-1, -1, P>(sLV, lane);
-        } else if constexpr (PCSEG_WS_FSM && T == 64) {
+        if constexpr (PCSEG_WS_FSM && T == 64) {
             if (dir == 0) changed = ws_quadrant_sweep<1, 1, P>(sLV, lane);
             else if (dir == 1) changed = ws_quadrant_sweep<1, -1, P>(sLV, lane);
             else if (dir == 2) changed = ws_quadrant_sweep<-1, 1, P>(sLV, lane);
@@ -704,7 +562,7 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
         const int r = r0 + rim_lr - 1, c = c0 + rim_lc - 1;
         // a tile that stopped early is not consistent inside: all four corner tiles have to look at it again
         bool ch = rim_thread && capped;
-        if (rim_thread && !capped && r >= 0 && r < H && c >= 0 && c < W) ch = WS_LEVEL(sLV[rim_lr * P + rim_lc]) != rim_before;
+        if (rim_thread && !capped && r >= 0 && r < H && c >= 0 && c < W) ch = sLV[rim_lr * P + rim_lc].x != rim_before;
         // the lanes of this thread's half edge inside its wave
         const unsigned long long mine = G::HE >= 64 ? ~0ull : (((1ull << (G::HE & 63)) - 1ull) << ((tid & 63) / G::HE * G::HE));
         const unsigned long long edge_changed = __ballot(ch) & mine;
@@ -724,14 +582,14 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             const int r = r0 + lr, c = c0 + 4 * q;
             const uint2 *src = sLV + (lr + 1) * P + 1 + 4 * q;
             if (r >= 0 && r < H && c >= 0 && c < W)
-                *reinterpret_cast<uint4 *>(L + fbase + rowoff(r, W) + c) = make_uint4(WS_LEVEL(src[0]), WS_LEVEL(src[1]), WS_LEVEL(src[2]), WS_LEVEL(src[3]));
+                *reinterpret_cast<uint4 *>(L + fbase + rowoff(r, W) + c) = make_uint4(src[0].x, src[1].x, src[2].x, src[3].x);
         }
         return;
     }
     for (int i = tid; i < T * T; i += NT) {
         int lr = i / T, lc = i % T;
         int r = r0 + lr, c = c0 + lc;
-        if (r >= 0 && r < H && c >= 0 && c < W) L[fbase + rowoff(r, W) + c] = WS_LEVEL(sLV[(lr + 1) * P + lc + 1]);
+        if (r >= 0 && r < H && c >= 0 && c < W) L[fbase + rowoff(r, W) + c] = sLV[(lr + 1) * P + lc + 1].x;
     }
 }
 
@@ -1154,7 +1012,7 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
                                                            const int *__restrict__ markers, const uint8_t *__restrict__ mask,
                                                            int *__restrict__ tie_flags, uint8_t *__restrict__ mark_active, int64_t n,
                                                            int W, int tilesX, int tilesY, int *__restrict__ exact_flags,
-                                                           uint8_t *__restrict__ in_bad = nullptr)
+                                                           uint8_t *__restrict__ in_bad = nullptr, uint8_t *__restrict__ mark_dirty = nullptr)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     ws_for_frames(frame_list, blockIdx.y, gridDim.y, [&](const int b) {
@@ -1176,7 +1034,10 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
     if (MODE == UF_REPAIR) {
         if (bad[groot]) {
             F[g] = mask[g] ? markers[g] : 0;
+            // the tile joins the second level's active set and carries a mark for its first round (two arrays: the set stays,
+            // the marks are taken down as tiles are visited)
             if (mark_active) mark_active[((int64_t)b * tilesY + r / WS_T) * tilesX + c / WS_T] = 1;
+            if (mark_dirty) mark_dirty[((int64_t)b * tilesY + r / WS_T) * tilesX + c / WS_T] = 1;
             if (in_bad) in_bad[g] = 1;
         }
         return;
@@ -1407,10 +1268,14 @@ __global__ void __launch_bounds__(256) ws_k2_init_kernel(const int *__restrict__
     });
 }
 
+// threads per tile of the second level: its tile pass is a handful of dependent LDS phases -- with 1024 threads a thread owns
+// 4 cells of the tile (256 threads, 16 cells each: 58 us a grid round against 32; profiles/r04/ab_logs/r4d_*, r4e_*)
+constexpr int K2T = 1024;
 struct WsK2Lds {
     unsigned sL[WS_N];
     unsigned sK[WS_N];
     uint8_t sLake[WS_N];
+    int par[WS_N];
 };
 
 // one tile of one second-level round (block-uniform control flow, like ws_relax_tile)
@@ -1439,12 +1304,12 @@ __device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *_
     {
         // the three arrays of the tile + halo as ONE batch of loads per thread (clamped addresses, no branch around a
         // load; see ws_relax_tile): a loop of dependent round trips here cost more than the sweeps
-        constexpr int TRIPS = (WS_S * WS_S + 255) / 256;
+        constexpr int TRIPS = (WS_S * WS_S + K2T - 1) / K2T;
         unsigned lv[TRIPS], kv[TRIPS], vv[TRIPS];
         uint8_t bv[TRIPS];
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
-            const int i = min((int)threadIdx.x + 256 * t, WS_S * WS_S - 1);
+            const int i = min((int)threadIdx.x + K2T * t, WS_S * WS_S - 1);
             const int r = r0 + i / WS_S - 1, c = c0 + i % WS_S - 1;
             const int64_t p = fbase + rowoff(min(max(r, 0), H - 1), W) + min(max(c, 0), W - 1);
             lv[t] = L[p];
@@ -1454,7 +1319,7 @@ __device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *_
         }
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
-            const int i = (int)threadIdx.x + 256 * t;
+            const int i = (int)threadIdx.x + K2T * t;
             if (i < WS_S * WS_S) {
                 const int lr = i / WS_S, lc = i % WS_S;
                 const int r = r0 + lr - 1, c = c0 + lc - 1;
@@ -1466,55 +1331,73 @@ __device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *_
         }
     }
     __syncthreads();
-    const SweepLine ln = ws_line();
-    // Which cells of the lane's line take their predecessor's key does not change during the visit (levels and lake flags
-    // are constants here): one 64-bit mask per lane, built once.  An iteration then only reads the keys -- eight at a time,
-    // all eight reads in flight together (what another wave writes meanwhile is picked up an iteration later: the update
-    // is a monotone min) -- instead of three dependent LDS reads per cell: a tile's fixed point is tens of iterations of
-    // one wave per direction, i.e. pure LDS latency (60 us per grid round before, for a few dozen tiles).
-    unsigned long long link = 0;
-    {
-        unsigned pl = sL[ln.start];
-        int i = ln.start;
-#pragma unroll 8
-        for (int k = 0; k < WS_T; ++k) {
-            i += ln.step;
-            const unsigned l = sL[i];
-            if (sLake[i] && l == pl) link |= 1ull << k;
-            pl = l;
-        }
-    }
-    bool changed_any = false;
-    for (int iter = 0; iter < 100000; ++iter) {
-        bool changed = false;
-        unsigned prevK = sK[ln.start];
-        int i = ln.start;
-#pragma unroll 1
-        for (int k0 = 0; k0 < WS_T; k0 += 8, i += 8 * ln.step) {
-            unsigned ck[8];
+    // The fixed point in ONE pass (round 4): an interior lake cell
+    // takes the smallest key among its same-level 4-neighbours, and lake cells of one level that touch take it from each
+    // other -- so every connected set of interior lake cells ends with the minimum over its own keys and the keys of the
+    // same-level cells around it (entries, which are not lake cells and keep their key, and halo cells, which belong to the
+    // neighbour tiles).  That is a union-find over the tile's lake cells plus one atomic min per cell at its root: a handful
+    // of LDS passes whatever the shape of the lake.  (Rounds 2-3 ran directional line sweeps here, one wave per direction: an
+    // iteration per turn of a winding lake -- tens of iterations of pure LDS latency, 127 us for the first grid round of the
+    // benchmark batch's 31 active tiles; four grid rounds 196 us against 128 now, profiles/r04/relax_sweep_variants_and_k2.diff.)
+    int *par = lds.par;
+    constexpr int CELLS = WS_T * WS_T / K2T;  // interior cells per thread
+    unsigned k_old[CELLS];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ck[j] = sK[i + (j + 1) * ln.step];
-            const unsigned bits = (unsigned)(link >> k0) & 255u;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (((bits >> j) & 1u) && prevK < ck[j]) {
-                    sK[i + (j + 1) * ln.step] = prevK;
-                    ck[j] = prevK;
-                    changed = true;
-                }
-                prevK = ck[j];
-            }
-        }
-        if (!__syncthreads_or(changed)) break;
-        changed_any = true;
+    for (int q = 0; q < CELLS; ++q) {
+        const int t = threadIdx.x + K2T * q, i = (t / WS_T + 1) * WS_P + t % WS_T + 1;
+        par[i] = sLake[i] ? i : -1;
+        k_old[q] = sK[i];
     }
+    __syncthreads();
+    // links between interior lake cells of one level: right and down (the other two are some cell's right / down)
+#pragma unroll
+    for (int q = 0; q < CELLS; ++q) {
+        const int t = threadIdx.x + K2T * q, lr = t / WS_T + 1, lc = t % WS_T + 1, i = lr * WS_P + lc;
+        if (!sLake[i]) continue;
+        const unsigned l = sL[i];
+        if (lc < WS_T && sLake[i + 1] && sL[i + 1] == l) unite_lds_halving(par, i, i + 1);
+        if (lr < WS_T && sLake[i + WS_P] && sL[i + WS_P] == l) unite_lds_halving(par, i, i + WS_P);
+    }
+    __syncthreads();
+    // every lake cell brings its own key and the keys of the same-level cells around it that are not members (entries,
+    // halo cells) to its root
+#pragma unroll
+    for (int q = 0; q < CELLS; ++q) {
+        const int t = threadIdx.x + K2T * q, lr = t / WS_T + 1, lc = t % WS_T + 1, i = lr * WS_P + lc;
+        if (!sLake[i]) continue;
+        const unsigned l = sL[i];
+        unsigned m = k_old[q];
+        const int nb[4] = {i - WS_P, i - 1, i + 1, i + WS_P};
+        const bool interior[4] = {lr > 1, lc > 1, lc < WS_T, lr < WS_T};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (sL[nb[d]] == l && !(interior[d] && sLake[nb[d]])) m = min(m, sK[nb[d]]);  // (members meet at the root anyway)
+        const int root = find_lds_halving(par, i);
+        if (root != i || m != k_old[q]) atomicMin(&sK[root], m);
+    }
+    __syncthreads();
+    bool changed = false;
+    unsigned k_new[CELLS];
+#pragma unroll
+    for (int q = 0; q < CELLS; ++q) {
+        const int t = threadIdx.x + K2T * q, i = (t / WS_T + 1) * WS_P + t % WS_T + 1;
+        k_new[q] = sLake[i] ? sK[find_lds_halving(par, i)] : k_old[q];
+        changed = changed || k_new[q] != k_old[q];
+    }
+    __syncthreads();  // every root has been read before a member overwrites its own cell (a root's own write is the value it holds)
+#pragma unroll
+    for (int q = 0; q < CELLS; ++q) {
+        const int t = threadIdx.x + K2T * q, i = (t / WS_T + 1) * WS_P + t % WS_T + 1;
+        if (k_new[q] != k_old[q]) sK[i] = k_new[q];
+    }
+    const bool changed_any = __syncthreads_or(changed);
     if (!changed_any) return;
     ws_mark_changed_edges(sK, (const unsigned *)K2 + fbase, dirty_out, b, tx, ty, tilesX, tilesY, r0, c0, H, W);
     __syncthreads();
     ws_store_tile(sK, K2 + fbase, r0, c0, H, W);
 }
 
-__global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
+__global__ void __launch_bounds__(K2T) ws_k2_relax_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
                                                            unsigned *__restrict__ K2, const uint8_t *__restrict__ active,
                                                            uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
                                                            int H, int W, int tilesX, int tilesY, const uint8_t *__restrict__ in_bad)
@@ -1527,7 +1410,7 @@ __global__ void __launch_bounds__(256) ws_k2_relax_kernel(const int *__restrict_
 }
 
 // the rest of the second-level fixed point after its grid rounds, one block per flagged frame (see ws_relax_tail_kernel)
-__global__ void __launch_bounds__(256) ws_k2_relax_tail_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val,
+__global__ void __launch_bounds__(K2T) ws_k2_relax_tail_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val,
                                                                 const unsigned *__restrict__ L, unsigned *__restrict__ K2,
                                                                 const uint8_t *__restrict__ active, uint8_t *__restrict__ dirtyA,
                                                                 uint8_t *__restrict__ dirtyB, int *__restrict__ not_converged,
@@ -1547,7 +1430,7 @@ __global__ void __launch_bounds__(256) ws_k2_relax_tail_kernel(const int *__rest
         __syncthreads();
         if (threadIdx.x == 0) tail_count = 0;
         __syncthreads();
-        for (int t = threadIdx.x; t < ntiles; t += 256)
+        for (int t = threadIdx.x; t < ntiles; t += K2T)
             if (marks[t] != 0 && act[t] != 0) {
                 const int k = atomicAdd(&tail_count, 1);
                 if (k < WS_TAIL_LIST) tail_list[k] = t;
@@ -1593,13 +1476,15 @@ __global__ void __launch_bounds__(256) ws_pack_kernel(const int *__restrict__ fr
 // verification builds of the second level run on whole flagged frames: every tile of such a frame becomes active and
 // its labels are reset to the seeds
 __global__ void __launch_bounds__(256) ws_activate_frames_kernel(const int *__restrict__ frame_list, const int *__restrict__ frame_flags, uint8_t *__restrict__ active,
-                                                                  const int *__restrict__ markers, const uint8_t *__restrict__ mask,
-                                                                  int *__restrict__ out, int64_t n, int W, int tilesX, int tilesY)
+                                                                  uint8_t *__restrict__ dirty, const int *__restrict__ markers,
+                                                                  const uint8_t *__restrict__ mask, int *__restrict__ out, int64_t n, int W,
+                                                                  int tilesX, int tilesY)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     ws_for_frames(frame_list, blockIdx.y, gridDim.y, [&](const int b) {
     if (i >= n || frame_flags[b] == 0) return;
     active[((int64_t)b * tilesY + (int)(i / W) / WS_T) * tilesX + (int)(i % W) / WS_T] = 1;
+    dirty[((int64_t)b * tilesY + (int)(i / W) / WS_T) * tilesX + (int)(i % W) / WS_T] = 1;
     out[(int64_t)b * n + i] = mask[(int64_t)b * n + i] ? markers[(int64_t)b * n + i] : 0;
     });
 }
@@ -2027,7 +1912,9 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     // kernel, the frames that need the second level are listed (and counted) on the device and the second-level
     // kernels cover the worst-case grid, from which the blocks of unlisted frames leave at once.
     const int max_rounds = (tilesX * tilesY + 64) * 64;
-    PCSEG_CHECK_HIP(hipMemsetAsync(changed, 0, sizeof(int) * WS_CHANGED_INTS, s));
+    // ONE fill for everything that starts at zero: the two mark buffers (round 0 visits every tile regardless), the active-tile
+    // set, the counters and both frame-flag arrays are carved next to each other (five separate fills were five launches)
+    PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, (size_t)((char *)(flags2 + B) - (char *)dirtyA), s));
     long long relax_launches = 0;
     if (mode == 1) {
         PCSEG_LAUNCH(ws_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, frame_stride, markers, mask, val, L,
@@ -2056,12 +1943,8 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                 lds_attr_set[dev].store(true);
             }
         }
-        // frame flags first: the tail kernels may raise flags2 (a fixed point they had to abandon)
-        PCSEG_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * B, s));
-        PCSEG_CHECK_HIP(hipMemsetAsync(flags2, 0, sizeof(int) * B, s));
-        // both mark buffers start empty (round 0 visits every tile regardless)
-        PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, ntiles_max, s));
-        PCSEG_CHECK_HIP(hipMemsetAsync(dirtyB, 0, ntiles_max, s));
+        // (frame flags and mark buffers: cleared by the one fill above -- the tail kernels may raise flags2 for a fixed point
+        // they had to abandon)
         {
             uint8_t *din = dirtyA, *dout = dirtyB;
             for (int round = 0; round < WS_GRID_ROUNDS; ++round) {
@@ -2119,9 +2002,9 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             }
             return PCSEG_OK;
         };
-        uint8_t *active = dirtyB;  // both mark buffers are empty again after a fixed point: free between the two loops
-        PCSEG_CHECK_HIP(hipMemsetAsync(active, 0, ntiles_max, s));
-        PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, ntiles_max, s));
+        // both mark buffers start the second level empty (a fixed point leaves them empty; one that was abandoned may not):
+        // they are carved next to each other -- one fill
+        PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, (size_t)((char *)dirtyB - (char *)dirtyA) + ntiles_max, s));
         int rc = assign_labels((const unsigned *)L, (const int *)nullptr, (const uint8_t *)nullptr, flags, true);
         if (rc) return rc;
         if (verify) {
@@ -2142,31 +2025,30 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             // it; the verification build checks keys over whole frames and keeps every lake)
             uint8_t *in_bad = verify ? nullptr : uf_bad2;
             PCSEG_LAUNCH(ws_uf_label_kernel<UF_REPAIR>, lgrid, dim3(256), 0, s, (const int *)frame_list, (const int *)uf_parent, out,
-                         (const uint8_t *)nullptr, uf_bad1, markers, mask, flags, active, npx, W, tilesX, tilesY, flags2, in_bad);
+                         (const uint8_t *)nullptr, uf_bad1, markers, mask, flags, active_tiles, npx, W, tilesX, tilesY, flags2, in_bad,
+                         dirtyA);
             PCSEG_CHECK_LAUNCH();
+            // (the repair pass writes the active set -- still all zero since the call's first fill -- and the first round's
+            // marks itself: two copies and a fill between the kernels gone)
             if (verify) {
                 // whole flagged frames, so that the explicit per-pixel check of the second level sees valid keys everywhere
-                PCSEG_LAUNCH(ws_activate_frames_kernel, lgrid, dim3(256), 0, s, (const int *)frame_list, (const int *)flags, active,
-                             markers, mask, out, npx, W, tilesX, tilesY);
+                PCSEG_LAUNCH(ws_activate_frames_kernel, lgrid, dim3(256), 0, s, (const int *)frame_list, (const int *)flags, active_tiles,
+                             dirtyA, markers, mask, out, npx, W, tilesX, tilesY);
                 PCSEG_CHECK_LAUNCH();
             }
-            // the fixed-point loop below reuses dirtyB: keep the active set in its own buffer
-            PCSEG_CHECK_HIP(hipMemcpyAsync(active_tiles, active, ntiles, hipMemcpyDeviceToDevice, s));
             PCSEG_LAUNCH(ws_k2_init_kernel, pgrid2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
                          (const unsigned *)L, markers, mask, (const uint8_t *)active_tiles, K2, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
-            // marks of the first round = the active tiles; the other buffer (it held the active set) starts empty
-            PCSEG_CHECK_HIP(hipMemcpyAsync(dirtyA, active_tiles, ntiles, hipMemcpyDeviceToDevice, s));
-            PCSEG_CHECK_HIP(hipMemsetAsync(dirtyB, 0, ntiles_max, s));
+            // marks of the first round = the active tiles (written by the repair pass); the other buffer is empty
             uint8_t *din = dirtyA, *dout = dirtyB;
             for (int round = 0; round < WS_K2_GRID_ROUNDS; ++round) {
-                PCSEG_LAUNCH(ws_k2_relax_kernel, tgrid, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
+                PCSEG_LAUNCH(ws_k2_relax_kernel, tgrid, dim3(K2T), 0, s, (const int *)frame_list, (const unsigned *)val,
                              (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, H, W, tilesX, tilesY,
                              (const uint8_t *)in_bad);
                 PCSEG_CHECK_LAUNCH();
                 uint8_t *t = din; din = dout; dout = t;
             }
-            PCSEG_LAUNCH(ws_k2_relax_tail_kernel, dim3(B), dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
+            PCSEG_LAUNCH(ws_k2_relax_tail_kernel, dim3(B), dim3(K2T), 0, s, (const int *)frame_list, (const unsigned *)val,
                          (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, changed + 6, flags2, H, W, tilesX, tilesY,
                          max_rounds, (const uint8_t *)in_bad);
             PCSEG_CHECK_LAUNCH();

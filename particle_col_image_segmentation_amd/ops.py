@@ -73,33 +73,6 @@ def classmap_label(stack):
     return z, labels, counts
 
 
-def classmap_label_regions(stack, cap, zero_sums=0):
-    """:func:`classmap_label` + the integer columns of the region table (A3) and the class at each region's first pixel in
-    ONE call: for W % 4 == 0 the table is filled by the pass that writes the final labels (csrc/ccl.hip,
-    ccl_relabel_stats_kernel) instead of a pass of its own over the label image.  Same results as ``classmap_label``
-    followed by ``region_reduce(labels, counts, cls=z, cap=cap, zero_sums=zero_sums)``.
-
-    Returns (denoised, labels, counts, stats int64 (B,cap,8), cls_out uint8 (B,cap), sums float64 (B,cap,zero_sums) | None,
-    overflow int32 (B,))."""
-    stack = _req(stack, torch.float32, 4)
-    B, C, H, W = stack.shape
-    dev = stack.device
-    z = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-    labels = torch.empty((B, H, W), dtype=torch.int32, device=dev)
-    counts = torch.empty((B,), dtype=torch.int32, device=dev)
-    stats = torch.empty((B, cap, 8), dtype=torch.int64, device=dev)
-    cls_out = torch.empty((B, cap), dtype=torch.uint8, device=dev)
-    sums = torch.empty((B, cap, int(zero_sums)), dtype=torch.float64, device=dev) if zero_sums else None
-    overflow = torch.empty((B,), dtype=torch.int32, device=dev)
-    lib = _lib.load()
-    nbytes = lib.pcseg_classmap_label_workspace_bytes(B, H, W)
-    ws = _ws(nbytes, dev)
-    _lib.check(lib.pcseg_classmap_label_regions_f32(_ptr(stack), C, _ptr(z), _ptr(labels), _ptr(counts), int(cap), _ptr(stats),
-                                                    _ptr(cls_out), _ptr(sums), int(zero_sums), _ptr(overflow), B, H, W, _ptr(ws),
-                                                    nbytes, _stream()), "classmap_label_regions")
-    return z, labels, counts, stats, cls_out, sums, overflow
-
-
 def _ccl(fn_name, x):
     x = _req(x, torch.uint8, 3)
     B, H, W = x.shape

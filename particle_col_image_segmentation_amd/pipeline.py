@@ -388,13 +388,13 @@ class FramePipeline:
         cap = self.cap or max(1024, (H * W) // 64)
         tb = self.tables_
         # ---- class map + denoise + label in one fused front end (ingest, A1, A2)
-        # ... and the region table's integer columns (A3) in the same call: the pass that writes the final labels fills them
-        # (one walk over the label image instead of two).  The isotope sums of the class components come from the fused
-        # plane pass at the end of the batch (_sums_stage), into the zeroed table made here
-        z, labels, counts, stats, cls_out, cc_sums, overflow = ops.classmap_label_regions(stack, cap, zero_sums=C)
+        z, labels, counts = ops.classmap_label(stack)
         res["denoised"] = z
         if denoised_ready is not None:
             denoised_ready.record(torch.cuda.current_stream())
+        # ---- region table (A3): the integer columns only (4 bytes per pixel); the isotope sums of the class components
+        # come from the fused plane pass at the end of the batch (_sums_stage), into the zeroed table made here
+        stats, cls_out, cc_sums, overflow = ops.region_reduce(labels, counts, cls=z, cap=cap, zero_sums=C)
         res.update(labels=labels, counts=counts, stats=stats, cls_out=cls_out, cc_sums=cc_sums, overflow=overflow)
         # ---- classification, cluster cell counts, region lists (A3 tail, A4)
         res.update(ops.classify_regions(stats, cls_out, counts, tb))

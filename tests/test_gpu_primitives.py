@@ -374,32 +374,6 @@ def test_classmap_label_fused_equals_separate_kernels(ops):
             np.testing.assert_array_equal(host(lab)[b], orc.label(den))
 
 
-def test_classmap_label_regions_equals_the_two_calls_and_the_oracle(ops):
-    """pcseg_classmap_label_regions_f32: the region table's integer columns filled BY the relabel pass (one walk over the label
-    image instead of two) against classmap_label + region_reduce and against the oracle's regionprops table -- full blocks,
-    heights that end inside a 4-row batch / a 32-row block, widths that are not a multiple of 1024 / 64, the ragged-width
-    and 7-plane fallbacks, a capacity below the label count (overflow flag, rows below cap still exact)."""
-    from particle_col_image_segmentation_amd import synth
-    for (H, W, C, cap) in ((160, 192, 5, 4096), (97, 132, 5, 4096), (66, 1024, 5, 4096), (33, 64, 4, 512), (70, 260, 3, 2048),
-                           (40, 74, 5, 1024), (40, 72, 7, 1024), (5, 4, 5, 64), (130, 2052, 5, 8192), (96, 128, 5, 7)):
-        st = synth.gen_batch(170, 2, H, W)
-        st = np.ascontiguousarray(st[:, :C]) if C <= 5 else np.ascontiguousarray(np.concatenate([st, st[:, :C - 5] * 0.5], axis=1))
-        z_ref, lab_ref, cnt_ref = ops.classmap_label(dev(st))
-        st_ref, cls_ref, sums_ref, ov_ref = ops.region_reduce(lab_ref, cnt_ref, cls=z_ref, cap=cap, zero_sums=3)
-        z, lab, cnt, stats, cls_out, sums, ov = ops.classmap_label_regions(dev(st), cap, zero_sums=3)
-        torch.cuda.synchronize()
-        assert torch.equal(z, z_ref) and torch.equal(lab, lab_ref) and torch.equal(cnt, cnt_ref), (H, W, C)
-        assert torch.equal(ov, ov_ref), (H, W, C, cap)
-        for b in range(2):
-            n = min(int(cnt[b]), cap)
-            np.testing.assert_array_equal(host(stats)[b, :n], host(st_ref)[b, :n], err_msg=str((H, W, C, cap, b)))
-            np.testing.assert_array_equal(host(cls_out)[b, :n], host(cls_ref)[b, :n])
-            assert not host(sums)[b, :n].any()
-            tab = orc.region_table(host(lab)[b], int(cnt[b]))
-            np.testing.assert_array_equal(host(stats)[b, :n], tab[:n], err_msg="oracle " + str((H, W, C, cap, b)))
-        assert int(ov.sum()) == (2 if cap == 7 else 0)
-
-
 def test_merge_groups(ops):
     from particle_col_image_segmentation_amd import synth
     st = synth.gen_batch(90, 2, 160, 160)
