@@ -123,10 +123,10 @@ def cpu_baseline(res, stack, cell_types, n_frames, tables=None):
             "reference_with_merge_as_written_over_port": ratio["reference_with_merge_over_oracle_with_merge"],
             "reference_with_merge_Mpixels_per_s_per_core_estimate": round(
                 H * W / 1e6 / (ratio["reference_chain_no_merge_s_per_frame"] + ratio["reference_merge_as_written_s"]), 4)}
-    return block, checked
+    return block, checked, refs
 
 
-def end_to_end_leg(args, stack, cell_types, pipe, dev, world, kernel_only_mpx):
+def end_to_end_leg(args, stack, cell_types, pipe, dev, world, kernel_only_mpx, refs=None):
     """What a dataset run costs beyond the kernels (BASELINE configs 3 / 5 code path, per rank): `distributed.run_sharded`
     over a dataset of 2 x lanes batches per rank (the resident batch stands in for every batch: generation is not what is
     measured) = kernel chain + device-side table assembly + table download + the all-gather of every table; and the
@@ -148,7 +148,20 @@ def end_to_end_leg(args, stack, cell_types, pipe, dev, world, kernel_only_mpx):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     e2e = n_frames * H * W / dt / 1e6
+    checked = None
+    if refs:
+        # the gathered tables themselves against the oracle (the CPU baseline's frames are the first frames of every batch of
+        # this dataset: the resident batch stands in for all of them) -- groups rows and the group columns of `cells` of the
+        # first AND the last batch, so the 1 024-frame run is not only timed
+        from oracle import parity
+        rank0 = int(os.environ.get("RANK", "0"))
+        if rank0 == 0:
+            ids0 = list(range(len(refs)))
+            last = (n_batches - 1) * B * world  # rank 0 owns frames i with i % world == 0: its k-th frame has id k * world
+            checked = parity.compare_tables(tabs, [i * world for i in ids0], refs)
+            checked += parity.compare_tables(tabs, [last + i * world for i in ids0], refs)
     block = {"dataset_frames": n_frames, "batches_per_rank": n_batches, "value": round(e2e, 1), "unit": "Mpixels/s",
+             "parity_checked_table_frames": checked,
              "includes": "kernel chain + device table assembly + table download + all-gather of rois/cells/groups/frames",
              "fraction_of_kernel_only": round(e2e / kernel_only_mpx, 3), "gathered_roi_rows": int(tabs["rois"].shape[0])}
     if world == 1:
@@ -472,17 +485,18 @@ def _run(args):
     # parity evidence of THIS run, before anything replays the pipeline's graphs again (a replay overwrites `res`):
     # world == 1: the CPU baseline's frames double as the check (32 by default); world > 1: no CPU baseline (rank 0 at
     # N = 1 only, by contract), but rank 0 still checks two frames of its timed batch against the oracle
-    cpu_block, checked = None, None
+    cpu_block, checked, cpu_refs = None, None, None
     if rank == 0 and not args.no_cpu_baseline:
         if world == 1:
-            cpu_block, checked = cpu_baseline(res, stack, ct, args.cpu_frames, tables)
+            cpu_block, checked, cpu_refs = cpu_baseline(res, stack, ct, args.cpu_frames, tables)
         else:
             from oracle import parity
             refs, _, _ = parity.run_oracle(stack[[0, B - 1]].cpu().numpy(), ct, merged=True, processes=2)
             checked = parity.compare(res, [0, B - 1], refs, sums_rtol=1e-6)
     e2e_block = None
     if not args.serial and not args.no_end_to_end:
-        e2e_block = end_to_end_leg(args, stack, ct, pipe, dev, world, world * B * H * W * args.steps / elapsed / 1e6)
+        e2e_block = end_to_end_leg(args, stack, ct, pipe, dev, world, world * B * H * W * args.steps / elapsed / 1e6,
+                                   refs=cpu_refs if world == 1 else None)
     if rank == 0:
         kernels, tiles_i, launches_i, steps_i = insitu
         if args.kernel_table:

@@ -338,17 +338,19 @@ __device__ __forceinline__ void relabel_chains(const int *par, int *lab, const i
             int nx[NCH];
 #pragma unroll
             for (int q = 0; q < NCH; ++q) nx[q] = root[q] >= 0 ? par[root[q]] : -1;
-            more = false;
+            // fenced (common.h, walk_ok), without branches: an entry above its index ends the chain where it stands and flags
+            // the frame
+            unsigned differ = 0, broke = 0;
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
-                // fenced (common.h, walk_ok): an entry above its index ends the chain where it stands and flags the frame
-                if (root[q] >= 0 && !walk_ok(root[q], nx[q])) {
-                    *bad = 1;
-                    nx[q] = root[q];
-                }
-                more = more || nx[q] != root[q];
+                const unsigned out = root[q] >= 0 && !walk_ok(root[q], nx[q]);
+                broke |= out;
+                nx[q] = out ? root[q] : nx[q];
+                differ |= (unsigned)(nx[q] ^ root[q]);
                 root[q] = nx[q];
             }
+            more = differ != 0;
+            if (broke) *bad = 1;
         }
     }
 #pragma unroll
@@ -365,8 +367,11 @@ __device__ __forceinline__ void relabel_chains(const int *par, int *lab, const i
         if (val[q] < 0) val[q] = off[q] - val[q];
 }
 
+// (launch bounds: the pass is dependent gathers hidden by occupancy, and residency of 256-thread workgroups is bounded by
+// SCALAR registers too -- min(8, 800 / (ceil(sgpr / 16) * 16 + 16)), MI355X_MICROARCH.md -- which the compiler only budgets when
+// it is told the target: 106 scalar registers = six workgroups per CU without the second argument, 78 = eight with it)
 template <typename Pred>
-__global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
+__global__ void __launch_bounds__(256, 8) ccl_relabel_quads_kernel(const int *__restrict__ parent, int *labels, const int *__restrict__ blockoff,
                                                                  Pred pred, int64_t n, int nblk, bool chase, int *__restrict__ counts)
 {
     const int b = blockIdx.y;
@@ -383,12 +388,15 @@ __global__ void __launch_bounds__(256) ccl_relabel_quads_kernel(const int *__res
     // frame -- is not a union-find entry; it becomes background and the frame's count -1
     int bad = 0;
 #pragma unroll
-    for (int q = 0; q < RELABEL_Q; ++q) {
+    for (int q = 0; q < RELABEL_Q; ++q) {  // (selects, not branches: sixteen `if`s in front of the chains cost the pass 15 us)
         const int i = (int)(i0 + (int64_t)q * SCAN_PIX);
-        if (pq[q].x >= 0 && !walk_ok(i, pq[q].x)) { bad = 1; pq[q].x = -1; }
-        if (pq[q].y >= 0 && !walk_ok(i + 1, pq[q].y)) { bad = 1; pq[q].y = -1; }
-        if (pq[q].z >= 0 && !walk_ok(i + 2, pq[q].z)) { bad = 1; pq[q].z = -1; }
-        if (pq[q].w >= 0 && !walk_ok(i + 3, pq[q].w)) { bad = 1; pq[q].w = -1; }
+        const int ox = pq[q].x >= 0 && !walk_ok(i, pq[q].x), oy = pq[q].y >= 0 && !walk_ok(i + 1, pq[q].y);
+        const int oz = pq[q].z >= 0 && !walk_ok(i + 2, pq[q].z), ow = pq[q].w >= 0 && !walk_ok(i + 3, pq[q].w);
+        bad |= ox | oy | oz | ow;
+        pq[q].x = ox ? -1 : pq[q].x;
+        pq[q].y = oy ? -1 : pq[q].y;
+        pq[q].z = oz ? -1 : pq[q].z;
+        pq[q].w = ow ? -1 : pq[q].w;
     }
     // First batch: the quads' first entries.  Neighbouring lanes mostly carry the same entry: only the first lane of each
     // run of equal entries walks, the others take its answer with one cross-lane read.

@@ -14,7 +14,14 @@
 namespace pcseg {
 
 constexpr int EDT_CH = 32;          // rows per bit word
-constexpr int EDT_RB = 8;           // rows per horizontal-pass block
+#ifndef PCSEG_EDT_REACH_ROWS
+#define PCSEG_EDT_REACH_ROWS 8
+#endif
+#ifndef PCSEG_EDT_REACH_OCC
+#define PCSEG_EDT_REACH_OCC 1
+#endif
+constexpr int EDT_RB = PCSEG_EDT_REACH_ROWS;  // rows per block of the threshold pass (a divisor of the 32-row word)
+static_assert(EDT_CH % EDT_RB == 0, "a block's rows lie in one bit word");
 constexpr unsigned G_INF = 0xFFFFu;  // "no zero pixel in this column"
 constexpr int EDT_STAGE_TRIPS = 4;   // column words a thread fetches as one batch when it stages a row block
 
@@ -58,8 +65,9 @@ struct FgNotInSetU8 {
 };
 
 // one thread per (word, column): fg bits of 32 rows
+// (launch bounds: 94 scalar registers = seven workgroups per CU without the second argument, 78 = eight with it)
 template <typename Fg>
-__global__ void __launch_bounds__(256) edt_bits_kernel(Fg fg, unsigned *__restrict__ bits, int H, int W, int nch)
+__global__ void __launch_bounds__(256, 8) edt_bits_kernel(Fg fg, unsigned *__restrict__ bits, int H, int W, int nch)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int ch = blockIdx.y, b = blockIdx.z;
@@ -335,7 +343,7 @@ __device__ __forceinline__ int reach_halfwidth(unsigned g, int R2)
 }
 
 template <typename Epi>
-__global__ void __launch_bounds__(256) edt_reach_kernel(const unsigned *__restrict__ bits, const uint16_t *__restrict__ up,
+__global__ void __launch_bounds__(256, PCSEG_EDT_REACH_OCC) edt_reach_kernel(const unsigned *__restrict__ bits, const uint16_t *__restrict__ up,
                                                          const uint16_t *__restrict__ dn, const int *__restrict__ any_bg,
                                                          Epi epi, unsigned long long *__restrict__ count, int H, int W, int nch)
 {

@@ -44,7 +44,10 @@ __device__ __forceinline__ unsigned class1(const float *__restrict__ fr, int C, 
 }
 
 template <int CT>
-__global__ void __launch_bounds__(256) classmap_median_ccl_kernel(const float *__restrict__ stack, int C, uint8_t *__restrict__ z,
+#ifndef PCSEG_FRONTEND_OCC
+#define PCSEG_FRONTEND_OCC 1  // A/B: 8 = 64 registers (20 bytes of scratch) and eight waves per SIMD instead of 67 and seven
+#endif
+__global__ void __launch_bounds__(256, PCSEG_FRONTEND_OCC) classmap_median_ccl_kernel(const float *__restrict__ stack, int C, uint8_t *__restrict__ z,
                                                                    int *__restrict__ parent, int H, int W)
 {
     // the histogram words are dead once the medians are out: the union-find parents take their place (18 KB per block

@@ -488,7 +488,10 @@ __device__ __forceinline__ void wave_commit(const RegionSlots &ls, long long *gs
     if (head && a.label > 0) run_commit(ls, gst, overflow, b, cap, a);
 }
 
-__global__ void __launch_bounds__(256, 4) region_stats_col_kernel(const int *__restrict__ labels, int H, int W, int cap,
+#ifndef PCSEG_STATS_OCC
+#define PCSEG_STATS_OCC 4
+#endif
+__global__ void __launch_bounds__(256, PCSEG_STATS_OCC) region_stats_col_kernel(const int *__restrict__ labels, int H, int W, int cap,
                                                                    long long *__restrict__ stats, int *__restrict__ overflow)
 {
     __shared__ int tags[RED_SLOTS];

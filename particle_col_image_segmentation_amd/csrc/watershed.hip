@@ -387,7 +387,8 @@ template <int T>
 __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, const bool FIRST, unsigned *__restrict__ val,
                                               unsigned *__restrict__ L, uint8_t *__restrict__ dirty_in,
                                               uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed, int H, int W,
-                                              const WsTiling &cur, const WsTiling &nxt, int max_iter, int tx, int ty, int b)
+                                              const WsTiling &cur, const WsTiling &nxt, int max_iter, int tx, int ty, int b,
+                                              int *__restrict__ list_out = nullptr, int *__restrict__ count_out = nullptr)
 {
     using G = RelaxGeom<T>;
     constexpr int S = G::S, P = G::P, NT = G::THREADS, QW = T / 4;  // QW: 16-byte quads per tile row
@@ -570,7 +571,16 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             // the tile of the other tiling that holds this corner quadrant (rows r0 + qy * T / 2 .., cols c0 + qx * T / 2 ..)
             const int oy = (r0 + qy * G::HE + nxt.off) / T, ox = (c0 + qx * G::HE + nxt.off) / T;
             if (oy >= 0 && oy < nxt.ny && ox >= 0 && ox < nxt.nx) {
-                dirty_out[((int64_t)b * nxt.ny + oy) * nxt.nx + ox] = 1;
+                const int64_t m = ((int64_t)b * nxt.ny + oy) * nxt.nx + ox;
+                if (list_out) {
+                    // the next round walks a LIST of marked tiles (ws_relax_list_kernel): the first marker of a tile appends it
+                    // (test-and-set on the mark's byte inside its 32-bit word: the mark arrays are 256-byte aligned)
+                    const unsigned bit = 1u << (8 * (int)(m & 3));
+                    const unsigned old = atomicOr(reinterpret_cast<unsigned *>(dirty_out + (m & ~(int64_t)3)), bit);
+                    if (!(old & bit)) list_out[atomicAdd(count_out, 1)] = (int)m;
+                } else {
+                    dirty_out[m] = 1;
+                }
             }
         }
     }
@@ -597,12 +607,40 @@ template <int T>
 __global__ void __launch_bounds__(RelaxGeom<T>::THREADS) ws_relax_kernel(WsInputs in, const bool FIRST, unsigned *__restrict__ val,
                                                                          unsigned *__restrict__ L, uint8_t *__restrict__ dirty_in,
                                                                          uint8_t *__restrict__ dirty_out, int *__restrict__ any_changed,
-                                                                         int H, int W, WsTiling cur, WsTiling nxt, int max_iter)
+                                                                         int H, int W, WsTiling cur, WsTiling nxt, int max_iter,
+                                                                         int *__restrict__ list_out, int *__restrict__ count_out)
 {
     extern __shared__ __attribute__((aligned(16))) uint2 relax_lds[];  // RelaxGeom<T>::N cells
     const TileIndex t = xcd_tile_index();  // a tile's halo is its neighbours' rim: keep them on one XCD's L2
     ws_relax_tile<T>(relax_lds + RelaxGeom<T>::PAD, in, FIRST, val, L, dirty_in, dirty_out, any_changed, H, W, cur, nxt, max_iter, t.x, t.y,
-                     t.z);
+                     t.z, list_out, count_out);
+}
+
+// Late rounds visit a few per cent of the tiles.  Launched over every tile they retire thousands of workgroups that read one
+// byte and leave -- each of which first has to be given 36 KB of LDS and four wave slots on a CU that seven other batches'
+// kernels are using (see WsTileList: the empty grids of the second level cost the STEP 3 %).  From round WS_LIST_FROM on a
+// round is a fixed small grid walking the list of tiles the round before marked (appended by the first marker of a tile).
+#ifndef PCSEG_WS_LIST_FROM
+#define PCSEG_WS_LIST_FROM 4  // first list-walking round (12 = never)
+#endif
+constexpr int WS_LIST_FROM = PCSEG_WS_LIST_FROM, WS_LIST_GRID = 1024;
+
+template <int T>
+__global__ void __launch_bounds__(RelaxGeom<T>::THREADS) ws_relax_list_kernel(WsInputs in, unsigned *__restrict__ val, unsigned *__restrict__ L,
+                                                                              uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
+                                                                              int *__restrict__ any_changed, int H, int W, WsTiling cur,
+                                                                              WsTiling nxt, int max_iter, const int *__restrict__ list_in,
+                                                                              const int *__restrict__ count_in, int *__restrict__ list_out,
+                                                                              int *__restrict__ count_out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint2 relax_lds[];
+    const int n = *count_in, per_frame = cur.nx * cur.ny;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int m = list_in[i], b = m / per_frame, t = m % per_frame;
+        ws_relax_tile<T>(relax_lds + RelaxGeom<T>::PAD, in, false, val, L, dirty_in, dirty_out, any_changed, H, W, cur, nxt, max_iter,
+                         t % cur.nx, t / cur.nx, b, list_out, count_out);
+        __syncthreads();  // the next listed tile reuses the LDS tile
+    }
 }
 
 // The fixed point is driven WITHOUT the host: a fixed number of grid rounds is enqueued (a round whose tiles carry no
@@ -680,6 +718,38 @@ static inline int ws_frame_span(const int *frame_list, int B) { return frame_lis
 __device__ __forceinline__ bool ws_active(const uint8_t *active, int b, int r, int c, int tilesX, int tilesY)
 {
     return active == nullptr || active[((int64_t)b * tilesY + r / WS_T) * tilesX + c / WS_T] != 0;
+}
+
+// The second level's work is a few dozen 64 x 64 tiles of a few frames (benchmark batch: 31 tiles in 7 frames).  Its passes
+// used to be launched over the worst-case grid of the listed frames -- every tile or pixel of up to eight frames, almost all
+// of whose blocks leave at once.  Alone that costs little; with eight batches in flight every such block still has to find a
+// CU with its LDS and wave slots free among the other batches' kernels (2 048 blocks of 1 024 threads and 58 KB for one
+// K2 round): same box, fewer grid rounds made the STEP faster although the serial time went up (4.53-4.57 ms against
+// 4.62-4.75, profiles/r04/ab_logs/r4f_*).  So the active tiles are listed once on the device (entry = frame * tiles per frame
+// + tile, the count in front of the list) and the second level's kernels are small fixed grids that walk the list.
+struct WsTileList {
+    const int *list;   // list[-1] = number of entries
+    int ntpf, tilesX;  // tiles per frame, tiles per tile row
+};
+constexpr int WS_TILE_GRID = 512;  // blocks of a list-walking launch (two per CU: a quantised batch lists every tile)
+
+template <typename Body>
+__device__ __forceinline__ void ws_for_tiles(const WsTileList &tl, Body &&body)
+{
+    const int n = tl.list[-1];
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int e = tl.list[i], b = e / tl.ntpf, t = e % tl.ntpf;
+        body(b, t % tl.tilesX, t / tl.tilesX);
+    }
+}
+
+__global__ void __launch_bounds__(256) ws_list_tiles_kernel(const int *__restrict__ frame_list, const uint8_t *__restrict__ active, int ntpf,
+                                                             int *__restrict__ tile_list)
+{
+    ws_for_frames(frame_list, blockIdx.x, gridDim.x, [&](const int b) {
+        for (int t = threadIdx.x; t < ntpf; t += 256)
+            if (active[(int64_t)b * ntpf + t]) tile_list[atomicAdd(&tile_list[-1], 1)] = b * ntpf + t;
+    });
 }
 
 // (2) label assignment by union-find: every non-seed reachable pixel is united with ALL its
@@ -921,7 +991,7 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
 // LIST = false: every frame (first level), one frame per grid slice, straight-line code (32 VGPRs, 8 waves / SIMD; the
 // looping variant needs 80); LIST = true: the listed frames, see ws_for_frames
 template <typename KeyT, bool LIST>
-__global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__ frame_list, const KeyT *__restrict__ K, const int *__restrict__ F,
+__global__ void __launch_bounds__(256) ws_uf_tile_kernel(WsTileList tiles, const KeyT *__restrict__ K, const int *__restrict__ F,
                                                           const uint8_t *__restrict__ active, int *__restrict__ parent,
                                                           uint8_t *__restrict__ minmask, uint8_t *__restrict__ bad, int H, int W,
                                                           int tilesX, int tilesY)
@@ -933,17 +1003,21 @@ __global__ void __launch_bounds__(256) ws_uf_tile_kernel(const int *__restrict__
         const TileIndex t = xcd_tile_index();
         ws_uf_tile_frame<KeyT>(sK, par, sM, t.z, t.x, t.y, K, F, active, parent, minmask, bad, H, W, tilesX, tilesY);
     } else {
-        const int n = frame_list[-1];
-        for (int gi = blockIdx.z; gi < n; gi += gridDim.z) {
-            ws_uf_tile_frame<KeyT>(sK, par, sM, frame_list[gi], blockIdx.x, blockIdx.y, K, F, active, parent, minmask, bad, H, W, tilesX,
-                                   tilesY);
-            __syncthreads();  // the next listed frame reuses the tile arrays
-        }
+        // the listed 64 x 64 tiles, two union-find tiles (64 x 32) each
+        ws_for_tiles(tiles, [&](const int b, const int tx, const int ty) {
+            for (int half = 0; half < WS_T / UF_TH; ++half) {
+                if ((ty * (WS_T / UF_TH) + half) * UF_TH < H)
+                    ws_uf_tile_frame<KeyT>(sK, par, sM, b, tx, ty * (WS_T / UF_TH) + half, K, F, active, parent, minmask, bad, H, W, tilesX,
+                                           tilesY);
+                __syncthreads();  // the next tile reuses the tile arrays
+            }
+        });
     }
 }
 
 // cross-tile links from the neighbour masks the tile pass left behind
-__global__ void __launch_bounds__(256) ws_uf_border_kernel(const int *__restrict__ frame_list, const uint8_t *__restrict__ minmask, const uint8_t *__restrict__ active,
+// (launch bounds: 104 scalar registers without them = six workgroups per CU for a pass of dependent walks; 78 with -- see label4_chains)
+__global__ void __launch_bounds__(256, 8) ws_uf_border_kernel(const int *__restrict__ frame_list, const uint8_t *__restrict__ minmask, const uint8_t *__restrict__ active,
                                                             int *__restrict__ parent, int H, int W, int tilesX, int tilesY,
                                                             int *__restrict__ exact_flags)
 {
@@ -1007,15 +1081,13 @@ enum { UF_OPTIMISTIC = 0, UF_REPAIR = 1, UF_DETECT = 2, UF_ASSIGN = 3 };
 //   UF_REPAIR also leaves, per pixel of a listed frame, "belongs to an unresolved component" in `in_bad` (if given): the
 //   second level's lake propagation only has to run inside those components (see ws_k2_relax_tile)
 template <int MODE>
-__global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict__ frame_list, const int *__restrict__ parent, int *__restrict__ F,
-                                                           const uint8_t *__restrict__ active, uint8_t *__restrict__ bad,
-                                                           const int *__restrict__ markers, const uint8_t *__restrict__ mask,
-                                                           int *__restrict__ tie_flags, uint8_t *__restrict__ mark_active, int64_t n,
-                                                           int W, int tilesX, int tilesY, int *__restrict__ exact_flags,
-                                                           uint8_t *__restrict__ in_bad = nullptr, uint8_t *__restrict__ mark_dirty = nullptr)
+__device__ __forceinline__ void ws_uf_label_pixel(const int b, const int64_t i, const int *__restrict__ parent, int *__restrict__ F,
+                                                  const uint8_t *__restrict__ active, uint8_t *__restrict__ bad,
+                                                  const int *__restrict__ markers, const uint8_t *__restrict__ mask,
+                                                  int *__restrict__ tie_flags, uint8_t *__restrict__ mark_active, int64_t n, int W,
+                                                  int tilesX, int tilesY, int *__restrict__ exact_flags, uint8_t *__restrict__ in_bad,
+                                                  uint8_t *__restrict__ mark_dirty)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    ws_for_frames(frame_list, blockIdx.y, gridDim.y, [&](const int b) {
     const int r = (int)(i / W), c = (int)(i % W);
     if (i >= n || !ws_active(active, b, r, c, tilesX, tilesY)) return;
     const int64_t fbase = (int64_t)b * n, g = fbase + i;
@@ -1054,6 +1126,39 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
         bad[groot] = 1;
         if (tie_flags[b] == 0) tie_flags[b] = 1;
     }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict__ frame_list, const int *__restrict__ parent, int *__restrict__ F,
+                                                           const uint8_t *__restrict__ active, uint8_t *__restrict__ bad,
+                                                           const int *__restrict__ markers, const uint8_t *__restrict__ mask,
+                                                           int *__restrict__ tie_flags, uint8_t *__restrict__ mark_active, int64_t n,
+                                                           int W, int tilesX, int tilesY, int *__restrict__ exact_flags,
+                                                           uint8_t *__restrict__ in_bad = nullptr, uint8_t *__restrict__ mark_dirty = nullptr)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    ws_for_frames(frame_list, blockIdx.y, gridDim.y, [&](const int b) {
+        ws_uf_label_pixel<MODE>(b, i, parent, F, active, bad, markers, mask, tie_flags, mark_active, n, W, tilesX, tilesY, exact_flags,
+                                in_bad, mark_dirty);
+    });
+}
+
+// the same pass over the listed 64 x 64 tiles only (second level: UF_DETECT, UF_ASSIGN)
+template <int MODE>
+__global__ void __launch_bounds__(256) ws_uf_label_tiles_kernel(WsTileList tiles, const int *__restrict__ parent, int *__restrict__ F,
+                                                                 const uint8_t *__restrict__ active, uint8_t *__restrict__ bad,
+                                                                 const int *__restrict__ markers, const uint8_t *__restrict__ mask,
+                                                                 int *__restrict__ tie_flags, int H, int W, int tilesX, int tilesY,
+                                                                 int *__restrict__ exact_flags)
+{
+    ws_for_tiles(tiles, [&](const int b, const int tx, const int ty) {
+        const int c = tx * WS_T + (threadIdx.x & 63);
+        for (int rr = threadIdx.x >> 6; rr < WS_T; rr += 4) {
+            const int r = ty * WS_T + rr;
+            if (r < H && c < W)
+                ws_uf_label_pixel<MODE>(b, (int64_t)r * W + c, parent, F, active, bad, markers, mask, tie_flags, nullptr, (int64_t)H * W, W,
+                                        tilesX, tilesY, exact_flags, nullptr, nullptr);
+        }
     });
 }
 
@@ -1068,40 +1173,54 @@ __global__ void __launch_bounds__(256) ws_uf_label_kernel(const int *__restrict_
 // pixels further on) and walks their chains -- parent entry, root, the root's label -- in lockstep: a lane with one
 // chain waits a memory latency per step (89 % of this kernel's wave cycles were waits).  A quad's chain belongs to its
 // first reachable pixel; a pixel with another parent entry walks on its own afterwards.
-constexpr int LABEL4_Q = 4;
+#ifndef PCSEG_LABEL4_Q
+#define PCSEG_LABEL4_Q 4
+#endif
+constexpr int LABEL4_Q = PCSEG_LABEL4_Q;
 
 // NCH chains in lockstep: root[q] (-1 = none) walks to its root, lab[q] becomes the root's label (0: no seed)
+// The fence of these chains costs TWO vector instructions a step and no compare: every load goes to a CLAMPED index (never
+// outside the frame, whatever the entry says) and an entry above its node's virtual index is cut down to the node itself by an
+// unsigned min -- the chain then simply ends there (strictly decreasing: never a cycle); `root - next < 0` accumulates as a
+// sign bit and one compare at the end raises the frame's flag.  (vwalk_ok written out per chain -- as `if`s or as selects fed
+// by compares -- parks sixteen lane masks in scalar register pairs: the kernel went from 96 to 106 scalar registers, i.e.
+// from seven to six workgroups per CU, and this pass is nothing but memory latency: 204 -> 265 us.  What the compiler's
+// occupancy figure does not show: residency of 256-thread workgroups is min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) --
+// MI355X_MICROARCH.md -- so `__launch_bounds__(256, 8)` below is what makes it budget scalar registers too: 78, eight
+// workgroups per CU.)
 template <int NCH>
 __device__ __forceinline__ void label4_chains(const int *par, const int *F, int64_t fbase, int n, int (&root)[NCH], int (&lab)[NCH], bool &bad)
 {
-#pragma unroll
-    for (int q = 0; q < NCH; ++q)
-        if (root[q] >= 0 && (root[q] & (UF_NS - 1)) >= n) {  // the pixel's own entry: any virtual index of the frame
-            bad = true;
-            root[q] = -1;
-        }
+    const int n1 = n - 1;
+    int viol = 0;
     bool more = true;
     while (more) {
         int nx[NCH];
 #pragma unroll
-        for (int q = 0; q < NCH; ++q) nx[q] = root[q] >= 0 ? par[root[q] & (UF_NS - 1)] : -1;
-        more = false;
+        for (int q = 0; q < NCH; ++q) nx[q] = root[q] >= 0 ? par[min(root[q] & (UF_NS - 1), n1)] : -1;
+        int differ = 0;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
-            if (root[q] >= 0 && !vwalk_ok(root[q], nx[q], n)) {  // fenced: the chain ends unlabelled, the frame is flagged
-                bad = true;
-                nx[q] = root[q] = -1;
-            }
-            more = more || nx[q] != root[q];
+            viol |= root[q] - nx[q];                               // sign bit: an entry above its node (both < 2^31; no chain: 0)
+            nx[q] = (int)min((unsigned)nx[q], (unsigned)root[q]);  // ... which ends the chain where it stands
+            differ |= nx[q] ^ root[q];
             root[q] = nx[q];
         }
+        more = differ != 0;
     }
+    bad = bad || viol < 0;
+    const int seeds_end = min(UF_NS, n);  // (a root is a seed pixel of the frame -- anything else is not to be trusted)
 #pragma unroll
     for (int q = 0; q < NCH; ++q)
-        lab[q] = (root[q] >= 0 && root[q] < UF_NS) ? F[fbase + root[q]] : 0;  // roots are labelled pixels, never changed by this pass
+        lab[q] = (root[q] >= 0 && root[q] < seeds_end) ? F[fbase + root[q]] : 0;  // roots are labelled pixels, never changed by this pass
 }
 
-__global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ minmask,
+#ifndef PCSEG_LABEL4_OCC
+// workgroups per CU the register allocator is asked for: 7 = 94 scalar / 69 vector registers, 217 us a launch; 8 = 78 / 64 with
+// 28 bytes of scratch, 254 us; without the argument 106 / 67 = six workgroups, 265 us (profiles/r04/ab_logs/r4i_*)
+#define PCSEG_LABEL4_OCC 7
+#endif
+__global__ void __launch_bounds__(256, PCSEG_LABEL4_OCC) ws_uf_label4_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ minmask,
                                                             int *F, uint8_t *__restrict__ bad, int *__restrict__ tie_flags,
                                                             int64_t n, int *__restrict__ exact_flags)
 {
@@ -1180,14 +1299,11 @@ __global__ void __launch_bounds__(256) ws_uf_label4_kernel(const int *__restrict
             if (x == lead[q]) { x_root = root[q]; x_lab = lab[q]; }
             else if (x == lead2[q]) { x_root = root2[q]; x_lab = lab2[q]; }
             else {  // (third: a quad with three different entries)
-                bool b3 = (x & (UF_NS - 1)) >= (int)n;
-                if (!b3) x = vwalk_root(par, x, (int)n, b3);
-                if (b3) {
-                    broken = true;
-                    continue;
-                }
+                // fenced like the chains: clamped index, an entry above its node ends the walk
+                int t;
+                while ((t = (int)min((unsigned)par[min(x & (UF_NS - 1), (int)n - 1)], (unsigned)x)) != x) x = t;
                 x_root = x;
-                x_lab = x < UF_NS ? F[fbase + x] : 0;
+                x_lab = (x >= 0 && x < min(UF_NS, (int)n)) ? F[fbase + x] : 0;
             }
             if (x_root < 0 || x_root >= UF_NS) continue;  // no labelled pixel in the component (or a chain that broke its fence)
             if (!seed) {
@@ -1242,29 +1358,29 @@ __global__ void __launch_bounds__(256) ws_check_kernel(const KeyT *__restrict__ 
 // K2(lake pixel) = min K2 over the neighbours of the same level (the earliest entry floods the whole lake).
 constexpr unsigned WS_SECONDARY = 0xFFFFFFFEu;
 
-__global__ void __launch_bounds__(256) ws_k2_init_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
+__global__ void __launch_bounds__(256) ws_k2_init_kernel(WsTileList tiles, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
                                                           const int *__restrict__ markers, const uint8_t *__restrict__ mask,
-                                                          const uint8_t *__restrict__ active, unsigned *__restrict__ K2,
-                                                          int H, int W, int tilesX, int tilesY)
+                                                          unsigned *__restrict__ K2, int H, int W)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (r >= H || c >= W) return;
-    ws_for_frames(frame_list, blockIdx.z, gridDim.z, [&](const int b) {
-    if (!ws_active(active, b, r, c, tilesX, tilesY)) return;
-    const int64_t i = (int64_t)b * H * W + (int64_t)r * W + c;
-    const unsigned l = L[i];
-    unsigned k = WS_INF;
-    if (l != WS_INF) {
-        if (mask[i] != 0 && markers[i] != 0) k = 0;
-        else if (val[i] == l) {
-            const unsigned lu = r > 0 ? L[i - W] : WS_INF, ld = r + 1 < H ? L[i + W] : WS_INF;
-            const unsigned ll = c > 0 ? L[i - 1] : WS_INF, lr = c + 1 < W ? L[i + 1] : WS_INF;
-            const unsigned m = min(min(lu, ld), min(ll, lr));
-            k = m < l ? max(m, 1u) : WS_SECONDARY;
+    ws_for_tiles(tiles, [&](const int b, const int tx, const int ty) {
+    const int c = tx * WS_T + (threadIdx.x & 63);
+    for (int rr = threadIdx.x >> 6; rr < WS_T; rr += 4) {
+        const int r = ty * WS_T + rr;
+        if (r >= H || c >= W) continue;
+        const int64_t i = (int64_t)b * H * W + (int64_t)r * W + c;
+        const unsigned l = L[i];
+        unsigned k = WS_INF;
+        if (l != WS_INF) {
+            if (mask[i] != 0 && markers[i] != 0) k = 0;
+            else if (val[i] == l) {
+                const unsigned lu = r > 0 ? L[i - W] : WS_INF, ld = r + 1 < H ? L[i + W] : WS_INF;
+                const unsigned ll = c > 0 ? L[i - 1] : WS_INF, lr = c + 1 < W ? L[i + 1] : WS_INF;
+                const unsigned m = min(min(lu, ld), min(ll, lr));
+                k = m < l ? max(m, 1u) : WS_SECONDARY;
+            }
         }
+        K2[i] = k;
     }
-    K2[i] = k;
     });
 }
 
@@ -1397,15 +1513,15 @@ __device__ __forceinline__ void ws_k2_relax_tile(WsK2Lds &lds, const unsigned *_
     ws_store_tile(sK, K2 + fbase, r0, c0, H, W);
 }
 
-__global__ void __launch_bounds__(K2T) ws_k2_relax_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
+__global__ void __launch_bounds__(K2T) ws_k2_relax_kernel(WsTileList tiles, const unsigned *__restrict__ val, const unsigned *__restrict__ L,
                                                            unsigned *__restrict__ K2, const uint8_t *__restrict__ active,
                                                            uint8_t *__restrict__ dirty_in, uint8_t *__restrict__ dirty_out,
                                                            int H, int W, int tilesX, int tilesY, const uint8_t *__restrict__ in_bad)
 {
     __shared__ WsK2Lds lds;
-    ws_for_frames(frame_list, blockIdx.z, gridDim.z, [&](const int b) {
-        ws_k2_relax_tile(lds, val, L, K2, active, dirty_in, dirty_out, H, W, tilesX, tilesY, blockIdx.x, blockIdx.y, b, in_bad);
-        __syncthreads();  // the next listed frame reuses the tile arrays
+    ws_for_tiles(tiles, [&](const int b, const int tx, const int ty) {
+        ws_k2_relax_tile(lds, val, L, K2, active, dirty_in, dirty_out, H, W, tilesX, tilesY, tx, ty, b, in_bad);
+        __syncthreads();  // the next listed tile reuses the tile arrays
     });
 }
 
@@ -1453,23 +1569,35 @@ __global__ void __launch_bounds__(K2T) ws_k2_relax_tail_kernel(const int *__rest
     });
 }
 
-// K64 = (L << 32) | K2 inside the active tiles; every other pixel of
-// a flagged frame gets (L, worst K2): it can sit in the halo of an active tile, where it must never look like a
-// minimum-key neighbour (it is not in the component, so its L is larger than the minimum anyway)
-__global__ void __launch_bounds__(256) ws_pack_kernel(const int *__restrict__ frame_list, const unsigned *__restrict__ L, const unsigned *__restrict__ K2,
-                                                       const int *__restrict__ frame_flags, const uint8_t *__restrict__ active,
-                                                       unsigned long long *__restrict__ K64, int64_t n, int W, int tilesX,
-                                                       int tilesY)
+// K64 = (L << 32) | K2 inside the active tiles.  A pixel just outside an active tile can sit in the halo of its union-find
+// tiles, where it must never look like a minimum-key neighbour (it is not in the component, so its L is larger than the
+// minimum anyway): the one-pixel ring around a listed tile gets (L, worst K2) wherever it does not belong to another active
+// tile (which packs its own pixels).  Nothing further out is ever read at this level.
+__global__ void __launch_bounds__(256) ws_pack_kernel(WsTileList tiles, const unsigned *__restrict__ L, const unsigned *__restrict__ K2,
+                                                       const uint8_t *__restrict__ active, unsigned long long *__restrict__ K64, int H, int W,
+                                                       int tilesX, int tilesY)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    ws_for_frames(frame_list, blockIdx.y, gridDim.y, [&](const int b) {
-    if (i >= n || frame_flags[b] == 0) return;
-    const int64_t g = (int64_t)b * n + i;
-    if (ws_active(active, b, (int)(i / W), (int)(i % W), tilesX, tilesY)) {
-        K64[g] = ((unsigned long long)L[g] << 32) | K2[g];
-    } else {
-        K64[g] = ((unsigned long long)L[g] << 32) | 0xFFFFFFFFull;
-    }
+    ws_for_tiles(tiles, [&](const int b, const int tx, const int ty) {
+        const int64_t fbase = (int64_t)b * H * W;
+        const int c = tx * WS_T + (threadIdx.x & 63);
+        for (int rr = threadIdx.x >> 6; rr < WS_T; rr += 4) {
+            const int r = ty * WS_T + rr;
+            if (r < H && c < W) {
+                const int64_t g = fbase + (int64_t)r * W + c;
+                K64[g] = ((unsigned long long)L[g] << 32) | K2[g];
+            }
+        }
+        // ring: thread t < 66 -> row above (t - 1 = column offset), 66..131 -> row below, 132..195 -> left column, 196..259 -> right
+        for (int t = threadIdx.x; t < 2 * (WS_T + 2) + 2 * WS_T; t += 256) {
+            int r, cc;
+            if (t < WS_T + 2) { r = ty * WS_T - 1; cc = tx * WS_T - 1 + t; }
+            else if (t < 2 * (WS_T + 2)) { r = ty * WS_T + WS_T; cc = tx * WS_T - 1 + (t - (WS_T + 2)); }
+            else if (t < 2 * (WS_T + 2) + WS_T) { r = ty * WS_T + (t - 2 * (WS_T + 2)); cc = tx * WS_T - 1; }
+            else { r = ty * WS_T + (t - 2 * (WS_T + 2) - WS_T); cc = tx * WS_T + WS_T; }
+            if (r < 0 || r >= H || cc < 0 || cc >= W || ws_active(active, b, r, cc, tilesX, tilesY)) continue;
+            const int64_t g = fbase + (int64_t)r * W + cc;
+            K64[g] = ((unsigned long long)L[g] << 32) | 0xFFFFFFFFull;
+        }
     });
 }
 
@@ -1815,6 +1943,11 @@ using namespace pcseg;
 #define PCSEG_WS_RELAX_TILE 64
 #endif
 constexpr int WS_ROUND0_SWEEPS = PCSEG_WS_ROUND0_SWEEPS;
+#ifndef PCSEG_WS_RELAX_LDS_PAD
+// A/B aid: extra dynamic LDS per relaxation block.  0 = four tiles per CU (4 x 36 KB); 16384 -> three, 40960 -> two: fewer of a
+// CU's waves belong to the relaxation and more of its LDS is left to the kernels of the other batches in flight
+#define PCSEG_WS_RELAX_LDS_PAD 0
+#endif
 
 // the watershed may be called from several host threads at once (FramePipeline's lanes)
 static std::atomic<long long> g_ws_counters[4];  // [0] unused (lives on the device), relax launches, calls, -
@@ -1861,7 +1994,8 @@ size_t pcseg_watershed_workspace_bytes(int B, int H, int W)
     size_t n = (size_t)B * H * W;
     int tilesX = (W + WS_T - 1) / WS_T, tilesY = (H + WS_T - 1) / WS_T;
     return 3 * align_up(n * 4) + 3 * align_up(n) + 2 * align_up((size_t)B * (tilesX + 1) * (tilesY + 1)) + align_up((size_t)B * tilesX * tilesY) + align_up(sizeof(int) * WS_CHANGED_INTS) + 2 * align_up(sizeof(int) * B) + align_up(sizeof(int) * ((size_t)B + 1)) +
-           align_up(n * 8) + align_up(n * 4);
+           align_up(n * 8) + align_up(n * 4) + align_up(sizeof(int) * ((size_t)B * tilesX * tilesY + 1)) +
+           align_up(sizeof(int) * 16) + 2 * align_up(sizeof(int) * (size_t)B * (tilesX + 1) * (tilesY + 1));
 }
 
 // grid rounds enqueued before the per-frame tail kernels take over (see ws_relax_tail_kernel): the benchmark batch needs
@@ -1897,6 +2031,10 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     int *flags = cv.take<int>(B);
     int *flags2 = cv.take<int>(B);
     int *frame_list = cv.take<int>(B + 1) + 1;  // frame_list[-1] = number of flagged frames (stays on the device)
+    int *round_count = cv.take<int>(16);            // [r] = tiles listed for relaxation round r (see ws_relax_list_kernel)
+    int *tile_list = cv.take<int>(ntiles + 1) + 1;  // the second level's active tiles, tile_list[-1] = their number
+    int *round_list[2] = {cv.take<int>(ntiles_max), cv.take<int>(ntiles_max)};
+    static_assert(WS_GRID_ROUNDS < 16, "one counter per grid round");
     unsigned long long *heap_key = cv.take<unsigned long long>(n);  // doubles as K64 of the second-level pass
     unsigned *heap_idx = cv.take<unsigned>(n);                      // doubles as K2
     int *uf_parent = cv.take<int>(n);
@@ -1914,7 +2052,8 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
     const int max_rounds = (tilesX * tilesY + 64) * 64;
     // ONE fill for everything that starts at zero: the two mark buffers (round 0 visits every tile regardless), the active-tile
     // set, the counters and both frame-flag arrays are carved next to each other (five separate fills were five launches)
-    PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, (size_t)((char *)(flags2 + B) - (char *)dirtyA), s));
+    // (... and, behind the frame list, the number of listed tiles)
+    PCSEG_CHECK_HIP(hipMemsetAsync(dirtyA, 0, (size_t)((char *)tile_list - (char *)dirtyA), s));
     long long relax_launches = 0;
     if (mode == 1) {
         PCSEG_LAUNCH(ws_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, frame_stride, markers, mask, val, L,
@@ -1935,9 +2074,11 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         static std::atomic<bool> lds_attr_set[64];
         {
             int dev = 0;
-            if (RG::LDS_BYTES > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !lds_attr_set[dev].load()) {
+            if (RG::LDS_BYTES + PCSEG_WS_RELAX_LDS_PAD > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !lds_attr_set[dev].load()) {
                 PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)ws_relax_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    (int)RG::LDS_BYTES));
+                                                    (int)(RG::LDS_BYTES + PCSEG_WS_RELAX_LDS_PAD)));
+                PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)ws_relax_list_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)(RG::LDS_BYTES + PCSEG_WS_RELAX_LDS_PAD)));
                 PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)ws_relax_tail_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     (int)RG::LDS_BYTES));
                 lds_attr_set[dev].store(true);
@@ -1949,8 +2090,16 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
             uint8_t *din = dirtyA, *dout = dirtyB;
             for (int round = 0; round < WS_GRID_ROUNDS; ++round) {
                 const WsTiling &cur = tilings[round & 1], &nxt = tilings[(round + 1) & 1];
-                PCSEG_LAUNCH(ws_relax_kernel<RT>, dim3(cur.nx, cur.ny, B), dim3(RG::THREADS), RG::LDS_BYTES, s, inputs, round == 0, val,
-                             L, din, dout, changed, H, W, cur, nxt, round == 0 ? WS_ROUND0_SWEEPS : PCSEG_WS_ROUND_SWEEPS);
+                // (a round's marks go into the next round's list once that round walks a list)
+                const bool lists_next = round + 1 >= WS_LIST_FROM && round + 1 < WS_GRID_ROUNDS;
+                int *lout = lists_next ? round_list[(round + 1) & 1] : nullptr, *cout = lists_next ? round_count + round + 1 : nullptr;
+                if (round >= WS_LIST_FROM)
+                    PCSEG_LAUNCH(ws_relax_list_kernel<RT>, dim3(WS_LIST_GRID), dim3(RG::THREADS), RG::LDS_BYTES + PCSEG_WS_RELAX_LDS_PAD, s, inputs,
+                                 val, L, din, dout, changed, H, W, cur, nxt, PCSEG_WS_ROUND_SWEEPS, (const int *)round_list[round & 1],
+                                 (const int *)(round_count + round), lout, cout);
+                else
+                PCSEG_LAUNCH(ws_relax_kernel<RT>, dim3(cur.nx, cur.ny, B), dim3(RG::THREADS), RG::LDS_BYTES + PCSEG_WS_RELAX_LDS_PAD, s, inputs, round == 0, val,
+                             L, din, dout, changed, H, W, cur, nxt, round == 0 ? WS_ROUND0_SWEEPS : PCSEG_WS_ROUND_SWEEPS, lout, cout);
                 PCSEG_CHECK_LAUNCH();
                 ++relax_launches;
                 uint8_t *t = din; din = dout; dout = t;
@@ -1966,16 +2115,17 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
         const dim3 bgrid_full((unsigned)((border_px + 255) / 256), B);
         // label assignment = union-find over "minimum-key neighbour" links.  A component holding two marker ids flags
         // its frame, stays unlabelled and (first level) marks its tiles active for the next level.
+        const WsTileList tiles{tile_list, tilesX * tilesY, tilesX};
         auto assign_labels = [&](auto *keys, const int *flist, const uint8_t *act, int *out_flags, bool first_level) -> int {
             using KeyT = std::remove_const_t<std::remove_pointer_t<decltype(keys)>>;
             const int span = ws_frame_span(flist, B);  // frame dimension of the grids (see ws_for_frames)
             const dim3 ugrid(ugrid_full.x, ugrid_full.y, span), bgrid(bgrid_full.x, span), lgrid(lgrid_full.x, span);
             uint8_t *level_bad = first_level ? uf_bad1 : uf_bad2;  // cleared by the tile pass, tile by tile
-            if (flist)
-                PCSEG_LAUNCH((ws_uf_tile_kernel<KeyT, true>), ugrid, dim3(256), 0, s, flist, (const KeyT *)keys, (const int *)out, act,
+            if (flist)  // second level: the listed tiles only
+                PCSEG_LAUNCH((ws_uf_tile_kernel<KeyT, true>), dim3(WS_TILE_GRID), dim3(256), 0, s, tiles, (const KeyT *)keys, (const int *)out, act,
                              uf_parent, uf_mask, level_bad, H, W, tilesX, tilesY);
             else
-                PCSEG_LAUNCH((ws_uf_tile_kernel<KeyT, false>), ugrid, dim3(256), 0, s, flist, (const KeyT *)keys, (const int *)out, act,
+                PCSEG_LAUNCH((ws_uf_tile_kernel<KeyT, false>), ugrid, dim3(256), 0, s, tiles, (const KeyT *)keys, (const int *)out, act,
                              uf_parent, uf_mask, level_bad, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
             if (border_px > 0) {
@@ -1993,11 +2143,11 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                              uf_bad1, markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY, flags2);
                 PCSEG_CHECK_LAUNCH();
             } else {
-                PCSEG_LAUNCH(ws_uf_label_kernel<UF_DETECT>, lgrid, dim3(256), 0, s, flist, (const int *)uf_parent, out, act, uf_bad2,
-                             markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY, flags2);
+                PCSEG_LAUNCH(ws_uf_label_tiles_kernel<UF_DETECT>, dim3(WS_TILE_GRID), dim3(256), 0, s, tiles, (const int *)uf_parent, out, act,
+                             uf_bad2, markers, mask, out_flags, H, W, tilesX, tilesY, flags2);
                 PCSEG_CHECK_LAUNCH();
-                PCSEG_LAUNCH(ws_uf_label_kernel<UF_ASSIGN>, lgrid, dim3(256), 0, s, flist, (const int *)uf_parent, out, act, uf_bad2,
-                             markers, mask, out_flags, (uint8_t *)nullptr, npx, W, tilesX, tilesY, flags2);
+                PCSEG_LAUNCH(ws_uf_label_tiles_kernel<UF_ASSIGN>, dim3(WS_TILE_GRID), dim3(256), 0, s, tiles, (const int *)uf_parent, out, act,
+                             uf_bad2, markers, mask, out_flags, H, W, tilesX, tilesY, flags2);
                 PCSEG_CHECK_LAUNCH();
             }
             return PCSEG_OK;
@@ -2036,13 +2186,17 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                              dirtyA, markers, mask, out, npx, W, tilesX, tilesY);
                 PCSEG_CHECK_LAUNCH();
             }
-            PCSEG_LAUNCH(ws_k2_init_kernel, pgrid2, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)val,
-                         (const unsigned *)L, markers, mask, (const uint8_t *)active_tiles, K2, H, W, tilesX, tilesY);
+            // the active tiles as a list: everything below walks it with small fixed grids (see WsTileList)
+            PCSEG_LAUNCH(ws_list_tiles_kernel, dim3(span), dim3(256), 0, s, (const int *)frame_list, (const uint8_t *)active_tiles,
+                         tilesX * tilesY, tile_list);
+            PCSEG_CHECK_LAUNCH();
+            PCSEG_LAUNCH(ws_k2_init_kernel, dim3(WS_TILE_GRID), dim3(256), 0, s, tiles, (const unsigned *)val, (const unsigned *)L, markers, mask,
+                         K2, H, W);
             PCSEG_CHECK_LAUNCH();
             // marks of the first round = the active tiles (written by the repair pass); the other buffer is empty
             uint8_t *din = dirtyA, *dout = dirtyB;
             for (int round = 0; round < WS_K2_GRID_ROUNDS; ++round) {
-                PCSEG_LAUNCH(ws_k2_relax_kernel, tgrid, dim3(K2T), 0, s, (const int *)frame_list, (const unsigned *)val,
+                PCSEG_LAUNCH(ws_k2_relax_kernel, dim3(WS_TILE_GRID), dim3(K2T), 0, s, tiles, (const unsigned *)val,
                              (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, H, W, tilesX, tilesY,
                              (const uint8_t *)in_bad);
                 PCSEG_CHECK_LAUNCH();
@@ -2052,8 +2206,8 @@ int pcseg_watershed4_f32(const float *img, int64_t frame_stride, const int32_t *
                          (const unsigned *)L, K2, (const uint8_t *)active_tiles, din, dout, changed + 6, flags2, H, W, tilesX, tilesY,
                          max_rounds, (const uint8_t *)in_bad);
             PCSEG_CHECK_LAUNCH();
-            PCSEG_LAUNCH(ws_pack_kernel, lgrid, dim3(256), 0, s, (const int *)frame_list, (const unsigned *)L, (const unsigned *)K2,
-                         (const int *)flags, (const uint8_t *)active_tiles, K64, npx, W, tilesX, tilesY);
+            PCSEG_LAUNCH(ws_pack_kernel, dim3(WS_TILE_GRID), dim3(256), 0, s, tiles, (const unsigned *)L, (const unsigned *)K2,
+                         (const uint8_t *)active_tiles, K64, H, W, tilesX, tilesY);
             PCSEG_CHECK_LAUNCH();
             rc = assign_labels((const unsigned long long *)K64, (const int *)frame_list, (const uint8_t *)active_tiles, flags2, false);
             if (rc) return rc;

@@ -73,3 +73,47 @@ def test_mosaic_4096_kernels():
     # dilation identity at full size: dilate(m, disk(2)) == EDT^2(~m) <= 4
     dil = ops.dilate_disk(z, 1 << 1, 2)[0].cpu().numpy().astype(bool)
     np.testing.assert_array_equal(dil, orc.edt_sq(zh != 1) <= 4)
+
+
+def test_run_sharded_2048_with_distances_matches_oracle():
+    """BASELINE config 5's code path at its frame shape: `run_sharded(..., distances=True)` over 2048 x 2048 x 5 frames (three
+    frames in two batches, the second a partial one) -- ROI rows, merged groups and the nearest-other-type distance table
+    (.m:260-268; PARITY UNPINNED: no MATLAB here, the oracle restates the script) against the per-frame oracle."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible")
+    from oracle import parity
+    from particle_col_image_segmentation_amd import synth
+    from particle_col_image_segmentation_amd.distributed import run_sharded
+    from particle_col_image_segmentation_amd.pipeline import FramePipeline, RATIOS_5
+    ct = dict(synth.CELL_TYPES_5)
+    H = W = 2048
+    dev = torch.device("cuda")
+    frames = synth.gen_batch_torch(6100, 3, H, W, dev)
+    pipe = FramePipeline(ct)
+    tabs = run_sharded(3, lambda ids: frames[list(ids)], pipe, batch=2, check=False, distances=True)
+    assert list(tabs["frames"][:, 0]) == [0.0, 1.0, 2.0]
+    slot = pipe.tables_.slot
+    checked = 0
+    for i in range(3):
+        st = frames[i].cpu().numpy()
+        try:
+            ref = orc.segment_frame(st, ct, merged=True)
+        except ValueError:
+            continue  # the reference's int(NaN) crash: no merged groups for this frame
+        checked += parity.compare_tables(tabs, [i], [parity.describe(ref, ct)])
+        rf = ref["refine"]
+        exp, _ = orc.roi_activity_table(rf["labels"], st, ratios=RATIOS_5)
+        rows = tabs["rois"][tabs["rois"][:, 0] == i]
+        np.testing.assert_array_equal(rows[:, 1], exp[:, 1])
+        np.testing.assert_allclose(rows[:, 5:10], exp[:, 2:7], rtol=1e-6)
+        # distances: rows of type slot 0, then of slot 1, from the positions the cells table holds
+        crow = tabs["cells"][tabs["cells"][:, 0] == i]
+        sl = slot[crow[:, 2].astype(np.int64)]
+        a, b = crow[sl == 0], crow[sl == 1]
+        drow = tabs["distances"][tabs["distances"][:, 0] == i]
+        if len(a) and len(b):
+            want = orc.nearest_distances(np.stack([a[:, 6] + 1.0, a[:, 5] + 1.0], 1), np.stack([b[:, 6] + 1.0, b[:, 5] + 1.0], 1))
+            np.testing.assert_array_equal(drow[:, 1], np.concatenate([a[:, 1], b[:, 1]]))
+            np.testing.assert_allclose(drow[:, 2], want, rtol=1e-12, atol=0)
+            assert len(drow) > 1000
+    assert checked >= 1
