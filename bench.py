@@ -84,6 +84,9 @@ def parse_args():
     ap.add_argument("--levels", type=int, default=0,
                     help="NOT the headline workload: quantise the boundary plane to k/LEVELS (random-forest-like vote "
                          "fractions); every frame then floods through ties and takes the watershed's exact path")
+    ap.add_argument("--watershed-mode", type=int, default=0,
+                    help="profiling aid for ABLATION builds (libraries that skip a phase: wrong labels, right timing): 2 = frames "
+                         "the proof fails on are reported, not recomputed by the exact flood.  The headline runs mode 0")
     return ap.parse_args()
 
 
@@ -414,7 +417,7 @@ def _run(args):
         stack[:, 3] = torch.round(stack[:, 3] * args.levels) / args.levels
     graph = bool(args.graph)
     pipe = FramePipeline(ct, overlap=not args.serial, lanes=args.lanes or None, multi_stream=not args.single_class_stream,
-                         graph=graph, merged=not args.no_merge)
+                         graph=graph, merged=not args.no_merge, watershed_mode=args.watershed_mode)
     res = None
     # setup (not warmup): in graph mode the first pass through each lane captures its graph (one plain run + the capture);
     # in eager mode two priming passes fill torch's caching allocator with every workspace block.  Then W untimed warmup

@@ -239,13 +239,18 @@ struct EpiFillParticle {
 // point are still true candidates (g^2 + k^2 of a real pixel), and no closer one is left.
 constexpr unsigned EDT_D2_INF = 0x40000000u;  // > any g^2 (g <= 32767); g^2 + k^2 stays below 2^32
 
+// guard cells either side of a staged row: the search reads five neighbouring cells from a CLAMPED base address without any
+// test (see the kernel).  (Round 3 had one guard cell and a branch per trip that clamped ten indices one by one near a row end,
+// and a division per pixel pair: 296 us a launch against 224, profiles/r04/ab_logs/r4k_*.)
+constexpr int EDT_GUARD = 4;
+
 template <typename Epi, int RB>
 __global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict__ bits, const uint16_t *__restrict__ up,
                                                        const uint16_t *__restrict__ dn, const int *__restrict__ any_bg,
                                                        Epi epi, unsigned long long *__restrict__ count, int H, int W, int nch)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned g2[];  // [RB][W + 2]
-    const int P = W + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned g2[];  // [RB][W + 2 * EDT_GUARD]
+    const int P = W + 2 * EDT_GUARD;
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * RB;
     const int ch = r0 / EDT_CH, j0 = r0 % EDT_CH;
@@ -271,45 +276,46 @@ __global__ void __launch_bounds__(256) edt_row_kernel(const unsigned *__restrict
                 for (int j = 0; j < RB; ++j)
                     if (j < nrows) {
                         const unsigned v = vdist(wordv[t], valid, j0 + j, uv[t], dv[t], rows_in_word);
-                        g2[j * P + c + 1] = v == G_INF ? EDT_D2_INF : v * v;
+                        g2[j * P + c + EDT_GUARD] = v == G_INF ? EDT_D2_INF : v * v;
                     }
             }
         }
     }
-    if (threadIdx.x < 2 * RB) g2[(threadIdx.x >> 1) * P + ((threadIdx.x & 1) ? W + 1 : 0)] = EDT_D2_INF;
+    if (threadIdx.x < 2 * EDT_GUARD * RB) {
+        const int j = threadIdx.x / (2 * EDT_GUARD), q = threadIdx.x % (2 * EDT_GUARD);
+        g2[j * P + (q < EDT_GUARD ? q : W + q)] = EDT_D2_INF;
+    }
     __syncthreads();
     const bool anybg = any_bg[b] != 0;
     const int kmax = epi.kmax(W);
     const int64_t fbase = (int64_t)b * H * W;
     unsigned long long cnt = 0;
     // a thread takes two neighbouring pixels: their candidate columns overlap (ten LDS reads per trip serve sixteen
-    // candidates) and the two min chains are independent
-    const int pairs_per_row = (W + 1) / 2;
-    for (int idx = threadIdx.x; idx < nrows * pairs_per_row; idx += 256) {
-        const int j = idx / pairs_per_row, c = (idx % pairs_per_row) * 2;
+    // candidates) and the two min chains are independent.  A wave walks whole rows (row = wave, wave + 4, ..; lane = pair):
+    // no division per pair
+    constexpr int WPR = RB >= 4 ? 1 : 4 / RB, RSTEP = 4 / WPR;  // waves per row; rows the block's four waves cover at a time
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = wave / WPR; j < nrows; j += RSTEP)
+    for (int c = 2 * (lane + 64 * (wave % WPR)); c < W; c += 128 * WPR) {
         const int64_t gi = fbase + rowoff((r0 + j), W) + c;
-        const unsigned *gr = g2 + j * P + 1;  // gr[-1] and gr[W] are the guard cells
+        const unsigned *gr = g2 + j * P + EDT_GUARD;  // gr[-EDT_GUARD .. -1] and gr[W .. W + EDT_GUARD - 1] are the guard cells
         const bool two = c + 1 < W;
         unsigned best0 = gr[c], best1 = two ? gr[c + 1] : 0u;
-        for (int k = 1; k <= kmax && (unsigned)(k * k) < max(best0, best1); k += 4) {
-            if (c + 1 - k < 0 && c + k >= W) break;
-            // columns c-k-3 .. c-k+1 on the left, c+k .. c+k+4 on the right.  Away from the row's ends (almost every trip)
-            // the ten reads are two base addresses plus constant offsets; only the trips that would run over an end clamp
-            // their indices one by one (ten clamps a trip were a fifth of the loop's instructions)
+        // Offsets k .. k + 3 of both pixels: columns c-k-3 .. c-k+1 on the left, c+k .. c+k+4 on the right -- two base
+        // addresses plus constant offsets.  The bases are CLAMPED to the row (0 and W - 1) instead of testing for the row's ends:
+        // a clamped read either lands in the guard cells (infinite) or on the end column, which is then NEARER to the pixel
+        // than the offset its candidate is priced with -- an over-estimate of a candidate that was examined at its true
+        // offset in an earlier trip, so the minimum is unchanged.  Past klim both pixels' offsets are outside the row on
+        // both sides (or beyond the cap): the loop's one compare covers that bound and "k^2 >= best".
+        const int klim = min(kmax, max(c + 1, W - 1 - c));
+        const unsigned lim2 = (unsigned)(klim + 1) * (unsigned)(klim + 1);
+        for (int k = 1; (unsigned)(k * k) < min(max(best0, best1), lim2); k += 4) {
+            const unsigned *pl = gr + max(c - k + 1, 0), *pr = gr + min(c + k, W - 1);
             unsigned gl[5], gq[5];
-            if (c - k - 3 >= -1 && c + k + 4 <= W) {
-                const unsigned *pl = gr + (c - k + 1), *pr = gr + (c + k);
 #pragma unroll
-                for (int t = 0; t < 5; ++t) {
-                    gl[t] = pl[-t];
-                    gq[t] = pr[t];
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 5; ++t) {
-                    gl[t] = gr[max(c - k + 1 - t, -1)];
-                    gq[t] = gr[min(c + k + t, W)];
-                }
+            for (int t = 0; t < 5; ++t) {
+                gl[t] = pl[-t];
+                gq[t] = pr[t];
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -539,17 +545,17 @@ static int edt_run(Fg fg, Epi epi, unsigned long long *count, int B, int H, int 
             PCSEG_LAUNCH(edt_count_kernel, dim3(B), dim3(64), 0, s, (const unsigned long long *)ws.block_counts, (int)g2.x, count);
         }
     } else {
-        // rows per block: as many as fit the LDS (uint32 per column and row, two guard cells per row)
+        // rows per block: as many as fit the LDS (uint32 per column and row, 2 * EDT_GUARD guard cells per row)
         auto launch_rows = [&](auto rb_tag) -> int {
             constexpr int RB = decltype(rb_tag)::value;
-            const size_t bytes = (size_t)RB * (W + 2) * sizeof(unsigned);
+            const size_t bytes = (size_t)RB * (W + 2 * EDT_GUARD) * sizeof(unsigned);
             if (bytes > 64 * 1024)
                 PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)edt_row_kernel<Epi, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
             PCSEG_LAUNCH((edt_row_kernel<Epi, RB>), dim3((H + RB - 1) / RB, B), dim3(256), bytes, s, ws.bits, ws.up, ws.dn, ws.any_bg, epi,
                          count, H, W, ws.nch);
             return PCSEG_OK;
         };
-        const size_t per_row = (size_t)(W + 2) * sizeof(unsigned);
+        const size_t per_row = (size_t)(W + 2 * EDT_GUARD) * sizeof(unsigned);
         int rc;
 #ifndef PCSEG_EDT_ROWS
 #define PCSEG_EDT_ROWS 4

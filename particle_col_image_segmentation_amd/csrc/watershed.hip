@@ -473,7 +473,15 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
                 const unsigned key = msk ? ws_key(hf) : WS_INF;
                 sLV[h_lr * P + h_lc] = make_uint2(msk && hm != 0 ? key : WS_INF, key);
             }
-        } else {
+        } else
+#ifdef PCSEG_EXP_RELAX_LOADS  // sensitivity build: a revisited tile is fetched this many times (what do its loads cost?)
+#pragma unroll 1
+        for (int load_rep = 0; load_rep < PCSEG_EXP_RELAX_LOADS; ++load_rep)
+#endif
+        {
+#ifdef PCSEG_EXP_RELAX_LOADS
+            asm volatile("" ::: "memory");
+#endif
             uint4 l4[TRIPS], v4[TRIPS];
 #pragma unroll
             for (int t = 0; t < TRIPS; ++t) {
@@ -586,6 +594,11 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
     }
     __syncthreads();
     if (in.vec) {
+#ifdef PCSEG_EXP_RELAX_STORES  // sensitivity build: a tile's levels are written this many times
+#pragma unroll 1
+        for (int store_rep = 0; store_rep < PCSEG_EXP_RELAX_STORES; ++store_rep) {
+            asm volatile("" ::: "memory");
+#endif
 #pragma unroll
         for (int t = 0; t < T * QW / NT; ++t) {
             const int idx = tid + NT * t, lr = idx / QW, q = idx % QW;
@@ -594,6 +607,9 @@ __device__ __forceinline__ void ws_relax_tile(uint2 *sLV, const WsInputs &in, co
             if (r >= 0 && r < H && c >= 0 && c < W)
                 *reinterpret_cast<uint4 *>(L + fbase + rowoff(r, W) + c) = make_uint4(src[0].x, src[1].x, src[2].x, src[3].x);
         }
+#ifdef PCSEG_EXP_RELAX_STORES
+        }
+#endif
         return;
     }
     for (int i = tid; i < T * T; i += NT) {
@@ -972,7 +988,9 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
             const bool same_run = (m & 2) || (ml & 4), same_run_up = (mu & 2) || (mul & 4), left_vertical = (ml & 1) || (mul & 8);
             if (same_run && same_run_up && left_vertical) continue;
         }
+#if !defined(PCSEG_EXP_UFTILE) || !(PCSEG_EXP_UFTILE & 1)  // (ablation builds: wrong labels, the pass's time without a phase)
         vunite_lds(par, par[t], par[t - UF_TW]);
+#endif
     }
     __syncthreads();
     for (int t = threadIdx.x; t < UF_TH * UF_TW; t += 256) {
@@ -980,7 +998,11 @@ __device__ __forceinline__ void ws_uf_tile_frame(KeyT *sK, int *par, uint8_t *sM
         if (r >= H || c >= W) continue;
         int v = -1;
         if (par[t] >= 0) {
+#if defined(PCSEG_EXP_UFTILE) && (PCSEG_EXP_UFTILE & 2)
+            const int root = par[t];
+#else
             const int root = vfind_lds(par, par[t]);
+#endif
             const int lt = root & (UF_LNS - 1);
             v = ((r0 + lt / UF_TW) * W + c0 + lt % UF_TW) | (root >= UF_LNS ? UF_NS : 0);
         }
@@ -1174,7 +1196,7 @@ __global__ void __launch_bounds__(256) ws_uf_label_tiles_kernel(WsTileList tiles
 // chain waits a memory latency per step (89 % of this kernel's wave cycles were waits).  A quad's chain belongs to its
 // first reachable pixel; a pixel with another parent entry walks on its own afterwards.
 #ifndef PCSEG_LABEL4_Q
-#define PCSEG_LABEL4_Q 4
+#define PCSEG_LABEL4_Q 3  // quads a lane carries (3 x 2 lockstep chains): 78 scalar / 53 vector registers, 194 us; 4: 94 / 69, 216 us
 #endif
 constexpr int LABEL4_Q = PCSEG_LABEL4_Q;
 
@@ -1216,9 +1238,10 @@ __device__ __forceinline__ void label4_chains(const int *par, const int *F, int6
 }
 
 #ifndef PCSEG_LABEL4_OCC
-// workgroups per CU the register allocator is asked for: 7 = 94 scalar / 69 vector registers, 217 us a launch; 8 = 78 / 64 with
-// 28 bytes of scratch, 254 us; without the argument 106 / 67 = six workgroups, 265 us (profiles/r04/ab_logs/r4i_*)
-#define PCSEG_LABEL4_OCC 7
+// workgroups per CU the register allocator is asked for.  With four quads a lane: 7 = 94 scalar / 69 vector registers, 217 us a
+// launch; 8 = 78 / 64 with 28 bytes of scratch, 254 us; without the argument 106 / 67 = six workgroups, 265 us.  With THREE quads
+// a lane eight workgroups fit without scratch: 194 us (profiles/r04/ab_logs/r4i_*, r4j_*)
+#define PCSEG_LABEL4_OCC 8
 #endif
 __global__ void __launch_bounds__(256, PCSEG_LABEL4_OCC) ws_uf_label4_kernel(const int *__restrict__ parent, const uint8_t *__restrict__ minmask,
                                                             int *F, uint8_t *__restrict__ bad, int *__restrict__ tie_flags,

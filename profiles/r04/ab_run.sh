@@ -5,9 +5,10 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; KEXPR=$2; PAT=$3; shift 3
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-Q="--no-shape-legs --no-cpu-baseline --secondary-batch 0 --batch64-frames 0 --graph-leg-steps 0 --no-end-to-end"
+Q="--no-shape-legs --no-cpu-baseline --secondary-batch 0 --batch64-frames 0 --graph-leg-steps 0 --no-end-to-end $Q_EXTRA"
 lib() { [ "$1" = main ] && echo "" || echo "$GRAFT_REPO_ROOT/ab/$1/libpcseg.so"; }
 for V in "$@"; do
+  [ -n "$NOTEST" ] && continue   # ablation builds (wrong results by construction): timing only
   echo "== tests $V"
   PCSEG_LIB=$(lib $V) timeout -k 10 600 python -m pytest tests/test_gpu_primitives.py tests/test_gpu_edge_cases.py -q -x -m gpu -k "$KEXPR" 2>&1 | tail -2 || exit 1
 done
