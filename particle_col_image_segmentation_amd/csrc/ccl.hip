@@ -921,7 +921,7 @@ __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__res
                                                                  int *__restrict__ parent, int *__restrict__ markers, int H, int W)
 {
     __shared__ int tile[LM_SH * LM_SW];
-    __shared__ uint8_t cand[LM_CH * LM_CW];  // tile + 1 ring: 0 inside and not a candidate, 1 candidate, 2 outside the image
+    __shared__ uint8_t cand[LM_CH * LM_CW];  // tile + 1 ring: 0 inside and not a candidate, 1 / 3 candidate (bit 0), 2 outside the image
     __shared__ int key[CCL_TILE];
     static_assert(LM_SH * LM_SW >= CCL_TILE, "the parents reuse the value tile");
     int *par = tile;  // the values are dead once the keys are out (20 KB per block instead of 28: 8 blocks per CU)
@@ -987,29 +987,51 @@ __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__res
         uint8_t state = 2;
         if (r >= 0 && r < H && c >= 0 && c < W) {
             const int *up = tile + i - LM_SW, *dn = tile + i + LM_SW;
+#if defined(PCSEG_EXP_LOCMAX) && (PCSEG_EXP_LOCMAX & 4)
+            const int m = max(up[0], dn[0]) + 40;
+#else
             const int m = max(max(max(up[-1], up[0]), max(up[1], tile[i - 1])), max(max(tile[i + 1], dn[-1]), max(dn[0], dn[1])));
-            state = m <= v ? 1 : 0;  // (OUTSIDE = INT_MIN is never higher)
+#endif
+            // 1: higher than all eight (nothing equal around it: neither a spoilt plateau nor a link), 3: a plateau pixel
+            state = m < v ? 1 : (m == v ? 3 : 0);  // (OUTSIDE = INT_MIN is never higher)
             any_differs = any_differs || v != first_value;
         }
         cand[t] = state;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < LM_TH * LM_TW; t += 256) {
+    // Equal-valued neighbours only exist around PLATEAU candidates (state 3), a small part of the few per cent of pixels that
+    // are candidates at all: only they look at their eight neighbours -- for an equal-valued NON-candidate (the plateau is
+    // spoilt) and for equal-valued candidates among the four neighbours that precede them (W, NW, N, NE: the links of the
+    // tile's union-find, one bit each, kept in a register until the value tile has become the parent array).
+    unsigned links = 0;  // 4 bits per pixel of this thread
+#pragma unroll
+    for (int kk = 0; kk < LM_TH * LM_TW / 256; ++kk) {
+        const int t = threadIdx.x + 256 * kk;
         const int lr = t / LM_TW, lc = t % LM_TW;
         const int r = r0 + lr, c = c0 + lc;
         int k = 0;
         if (r < H && c < W) {
             const int i = (lr + 2) * LM_SW + lc + 2, j = (lr + 1) * LM_CW + lc + 1;
             const int v = tile[i];
-            const bool is_cand = cand[j] == 1;
+            const uint8_t st = cand[j];
+            const bool is_cand = (st & 1) != 0;
             bool touches = false;
-            if (is_cand) {
+#if defined(PCSEG_EXP_LOCMAX) && (PCSEG_EXP_LOCMAX & 1)  // (ablation builds, profiles/r04/time_ops.py locmax: the pass without a phase)
+            if (false) {
+#else
+            if (st == 3) {
+#endif
 #pragma unroll
                 for (int dr = -1; dr <= 1; ++dr)
 #pragma unroll
                     for (int dc = -1; dc <= 1; ++dc) {
                         if (dr == 0 && dc == 0) continue;
-                        touches = touches || (cand[j + dr * LM_CW + dc] == 0 && tile[i + dr * LM_SW + dc] == v);
+                        const bool eq = tile[i + dr * LM_SW + dc] == v;
+                        const uint8_t sn = cand[j + dr * LM_CW + dc];
+                        touches = touches || (eq && sn == 0);
+                        // a link to a PRECEDING neighbour inside the tile (the border pass makes the links across tiles)
+                        if ((dr < 0 || (dr == 0 && dc < 0)) && eq && (sn & 1) && lr + dr >= 0 && lc + dc >= 0 && lc + dc < LM_TW)
+                            links |= 1u << (4 * kk + (dr == 0 ? 0 : dc + 2));  // bit 0: W, 1: NW, 2: N, 3: NE
                     }
             }
             // key must be non-zero for candidates and equal exactly when the values are equal (values > INT_MIN)
@@ -1030,7 +1052,26 @@ __global__ void __launch_bounds__(256) locmax_candidates_kernel(const int *__res
     }
     if (__any(any_differs) && lane_id() == 0 && nonconst[ti.z] == 0) nonconst[ti.z] = 1;
     __syncthreads();
-    ccl_tile_unions<true>(key, par);
+    // tile pass of the candidates' plateaus: every pixel its own node, then the recorded links (candidates are sparse and their
+    // plateaus small: the run-based tile pass of the dense labellings -- ballots and link tests for all 2 048 pixels -- cost 46 us
+    // of this kernel's 256, profiles/r04/ab_logs/r4n_*)
+    for (int i = threadIdx.x; i < CCL_TILE; i += 256) par[i] = i;
+    __syncthreads();
+#if !(defined(PCSEG_EXP_LOCMAX) && (PCSEG_EXP_LOCMAX & 2))
+    if (links) {
+#pragma unroll
+        for (int kk = 0; kk < LM_TH * LM_TW / 256; ++kk) {
+            const unsigned m = (links >> (4 * kk)) & 15u;
+            if (!m) continue;
+            const int i = threadIdx.x + 256 * kk;
+            if (m & 1u) unite_lds_pair(par, i, i - 1);
+            if (m & 2u) unite_lds_pair(par, i, i - CCL_TW - 1);
+            if (m & 4u) unite_lds_pair(par, i, i - CCL_TW);
+            if (m & 8u) unite_lds_pair(par, i, i - CCL_TW + 1);
+        }
+    }
+    __syncthreads();
+#endif
     // tile-local roots -> frame-wide parent entries, candidates only
     for (int i = threadIdx.x; i < CCL_TILE; i += 256) {
         const int r = r0 + i / CCL_TW, c = c0 + i % CCL_TW;

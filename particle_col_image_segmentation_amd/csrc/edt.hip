@@ -402,14 +402,22 @@ __global__ void __launch_bounds__(256, PCSEG_EDT_REACH_OCC) edt_reach_kernel(con
 #pragma unroll
                 for (int j = 0; j < EDT_RB; ++j)
                     if (j < nrows) {
+#if defined(PCSEG_EXP_REACH) && (PCSEG_EXP_REACH & 2)  // (... without the bit scans of its staging)
+                        const unsigned v = ((wordv[t] >> (j0 + j)) & 1u) ? min(uv[t] + dv[t], 0x7FFFu) : 0u;
+#else
                         const unsigned v = min(vdist(wordv[t], valid, j0 + j, uv[t], dv[t], rows_in_word), 0x7FFFu);
+#endif
                         g[j * W4 + c] = (uint16_t)v;  // bit 15 stays free
                         near = near || v <= gmax;
                     }
             }
         }
     }
+#if defined(PCSEG_EXP_REACH) && (PCSEG_EXP_REACH & 1)  // (ablation builds, profiles/r04/time_ops.py: the pass without its scans)
+    const bool any_near = __syncthreads_or(near) && false;
+#else
     const bool any_near = __syncthreads_or(near);
+#endif
     const bool anybg = any_bg[b] != 0;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int nchunks = (W + WAVE - 1) / WAVE;

@@ -112,7 +112,11 @@ __global__ void __launch_bounds__(256, PCSEG_FRONTEND_OCC) classmap_median_ccl_k
         const int lr = s / (MED_TW / 4), lc = (s % (MED_TW / 4)) * 4;
         const int r = r0 + lr, c = c0 + lc;
         uint32_t med[4] = {0, 0, 0, 0};
+#if defined(PCSEG_EXP_FRONTEND) && (PCSEG_EXP_FRONTEND & 1)  // (ablation builds, profiles/r04/time_ops.py: the kernel's time without a phase)
+        med[0] = med[1] = med[2] = med[3] = 1 + ((lr + lc) & 1);
+#else
         if (r < H && c < W) median5_hot_strip(hot, lr, lc, med);
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) key[lr * CCL_TW + lc + j] = (r < H && c + j < W) ? (int)med[j] : 0;
         if (r < H && c < W) {
@@ -125,7 +129,12 @@ __global__ void __launch_bounds__(256, PCSEG_FRONTEND_OCC) classmap_median_ccl_k
     }
     __syncthreads();
     // (3) tile pass of the equal-value 8-connected labelling
+#if defined(PCSEG_EXP_FRONTEND) && (PCSEG_EXP_FRONTEND & 2)
+    for (int i = threadIdx.x; i < CCL_TILE; i += 256) par[i] = i;
+    __syncthreads();
+#else
     ccl_tile_unions<true>(key, par);
+#endif
     ccl_tile_store(key, par, parent, (int64_t)b * n, r0, c0, H, W);
 }
 
