@@ -170,7 +170,9 @@ def test_edt(ops, primitives):
         d2 = host(ops.edt_sq(one(c["inp"])))[0]
         np.testing.assert_array_equal(np.sqrt(d2.astype(np.float64)), c["out"])
     for (b, h, w, p) in [(3, 100, 131, 0.97), (2, 257, 300, 0.999), (2, 33, 1025, 0.9), (1, 1024, 1024, 0.9995),
-                         (2, 40, 40, 1.0), (2, 31, 65, 0.5)]:
+                         (2, 40, 40, 1.0), (2, 31, 65, 0.5), (1, 9, 12001, 0.9998), (1, 5, 7, 0.8), (1, 3, 2, 0.5)]:
+        # (12001 columns: a staged row no longer fits four to a block -- the one-row form of the horizontal pass; 7 and 2
+        # columns: every read of the search is a clamped one)
         m = RNG.random((b, h, w)) < p
         d2 = host(ops.edt_sq(dev(m)))
         dc = host(ops.edt_sq(dev(m), cap=50))
