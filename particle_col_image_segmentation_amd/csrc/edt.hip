@@ -17,6 +17,9 @@ constexpr int EDT_CH = 32;          // rows per bit word
 #ifndef PCSEG_EDT_REACH_ROWS
 #define PCSEG_EDT_REACH_ROWS 8
 #endif
+#ifndef PCSEG_EDT_REACH_BITS
+#define PCSEG_EDT_REACH_BITS 1  // 0 (A/B builds): every threshold epilogue takes the row-block pass (edt_reach_kernel)
+#endif
 #ifndef PCSEG_EDT_REACH_OCC
 #define PCSEG_EDT_REACH_OCC 1
 #endif
@@ -66,8 +69,9 @@ struct FgNotInSetU8 {
 
 // one thread per (word, column): fg bits of 32 rows
 // (launch bounds: 94 scalar registers = seven workgroups per CU without the second argument, 78 = eight with it)
+// any_bg (may be null): any_bg[b] = 1 if the frame has a zero pixel at all -- one plain store per wave that saw one
 template <typename Fg>
-__global__ void __launch_bounds__(256, 8) edt_bits_kernel(Fg fg, unsigned *__restrict__ bits, int H, int W, int nch)
+__global__ void __launch_bounds__(256, 8) edt_bits_kernel(Fg fg, unsigned *__restrict__ bits, int *__restrict__ any_bg, int H, int W, int nch)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int ch = blockIdx.y, b = blockIdx.z;
@@ -90,11 +94,16 @@ __global__ void __launch_bounds__(256, 8) edt_bits_kernel(Fg fg, unsigned *__res
         }
     }
     bits[((int64_t)b * nch + ch) * W + c] = word;
+    if (any_bg) {
+        const int rows = min(EDT_CH, H - r0);
+        const bool zero = (~word & (rows >= 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u))) != 0;
+        if (__any(zero) && __ffsll((long long)__ballot(true)) - 1 == lane_id()) any_bg[b] = 1;
+    }
 }
 
 // byte inputs with W % 4 == 0: a lane takes four adjacent columns (one 4-byte load per row, one 16-byte store)
 template <typename Fg>
-__global__ void __launch_bounds__(256) edt_bits4_kernel(Fg fg, unsigned *__restrict__ bits, int H, int W, int nch)
+__global__ void __launch_bounds__(256) edt_bits4_kernel(Fg fg, unsigned *__restrict__ bits, int *__restrict__ any_bg, int H, int W, int nch)
 {
     const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int ch = blockIdx.y, b = blockIdx.z;
@@ -118,6 +127,10 @@ __global__ void __launch_bounds__(256) edt_bits4_kernel(Fg fg, unsigned *__restr
     const unsigned valid = rows >= 32 ? 0xFFFFFFFFu : ((1u << rows) - 1u);
     w0 &= valid; w1 &= valid; w2 &= valid; w3 &= valid;
     *reinterpret_cast<uint4 *>(bits + ((int64_t)b * nch + ch) * W + c) = make_uint4(w0, w1, w2, w3);
+    if (any_bg) {
+        const bool zero = ((~w0 | ~w1 | ~w2 | ~w3) & valid) != 0;
+        if (__any(zero) && __ffsll((long long)__ballot(true)) - 1 == lane_id()) any_bg[b] = 1;
+    }
 }
 
 // per column: distance from the first row of each word to the nearest zero above it (up),
@@ -205,12 +218,14 @@ struct EpiDilate {
     static constexpr bool kInput = false;
     uint8_t *out;
     int r2;
-    __device__ __forceinline__ int R2() const { return r2; }
+    __host__ __device__ __forceinline__ int R2() const { return r2; }
     __device__ __forceinline__ const uint8_t *input() const { return nullptr; }
     __device__ __forceinline__ uint8_t decide(uint8_t, bool within, bool any_bg, int, int, unsigned long long &) const
     {
         return (any_bg && within) ? 1 : 0;  // empty set dilates to the empty set
     }
+    // four pixels at once (a frame WITH a zero pixel): w4 = the verdicts, 0 / 1 per byte
+    __device__ __forceinline__ unsigned decide4(unsigned, unsigned w4, unsigned long long &) const { return w4; }
 };
 struct EpiFillParticle {
     static constexpr bool kThreshold = true;
@@ -218,7 +233,7 @@ struct EpiFillParticle {
     const uint8_t *ds;
     uint8_t *out;
     int cell_label, overlap_label, r2, thr2;  // overlap if d2 <= r2 (dilation) or d2 < thr2 (distance)
-    __device__ __forceinline__ int R2() const { return max(r2, thr2 - 1); }
+    __host__ __device__ __forceinline__ int R2() const { return max(r2, thr2 - 1); }
     __device__ __forceinline__ const uint8_t *input() const { return ds; }
     __device__ __forceinline__ uint8_t decide(uint8_t z, bool within, bool any_bg, int r, int c, unsigned long long &cnt) const
     {
@@ -229,6 +244,16 @@ struct EpiFillParticle {
             if (ov) { z = (uint8_t)overlap_label; ++cnt; }
         }
         return z;
+    }
+    // four pixels at once (a frame WITH a zero pixel): z4 = the input bytes, w4 = the verdicts, 0 / 1 per byte
+    __device__ __forceinline__ unsigned decide4(unsigned z4, unsigned w4, unsigned long long &cnt) const
+    {
+        const unsigned x = z4 ^ (0x01010101u * (unsigned)cell_label);
+        unsigned nz = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;  // bit 7 of a byte: its low seven bits are not all zero (no carry leaves a byte)
+        nz = ~(nz | x | 0x7F7F7F7Fu);                   // 0x80 exactly where the byte of x is zero, i.e. the pixel is a cell pixel
+        const unsigned hit = (nz >> 7) & w4;
+        cnt += __popc(hit);
+        return z4 ^ (hit * (unsigned)(cell_label ^ overlap_label));  // a hit byte holds cell_label: it becomes overlap_label
     }
 };
 
@@ -485,6 +510,129 @@ __global__ void __launch_bounds__(64) edt_count_kernel(const unsigned long long 
     if (threadIdx.x == 0) count[b] += s;
 }
 
+// ---- threshold epilogues with a SMALL reach (floor(sqrt(R2)) <= 31: disk(2), fill_particle_area's radius 20), on the BIT
+// words.  "Some zero pixel within sqrt(R2) of (r, c)" is the union over the column offsets dx of "column c + dx has a zero
+// pixel within h(|dx|) = floor(sqrt(R2 - dx^2)) rows of r" -- and the second statement for all 32 rows of a bit word at once is
+// the word of zero bits dilated vertically by h(|dx|) rows: three word operations per row of reach, whatever the image
+// holds.  A block takes 448 columns of one word row: (1) every column (and 32 columns either side) dilates its word one
+// row at a time and leaves the dilations the offsets ask for in LDS, (2) every column ORs the 2 D + 1 entries its
+// neighbours left for it, (3) the verdict bits meet the input bytes four columns at a time.  No distances, no staged rows,
+// no scans: the row-block pass this replaces (edt_reach_kernel) spent 78 of its 148 us a launch in prefix scans and 20 in
+// bit scans (profiles/r04/ab_logs/r4n_*), 0.97 of its SIMD-cycles issuing vector instructions.
+constexpr int RBIT_TC = 448, RBIT_HALO = 32, RBIT_THREADS = RBIT_TC + 2 * RBIT_HALO, RBIT_MAXD = 31;
+struct ReachTab {
+    int D, nslots;
+    int tc;  // columns a block finishes: W split evenly over ceil(W / 448) blocks, a multiple of 4
+    // hd[d] = rows a zero pixel reaches at column offset d (falls with d).  The kernel needs no table, only two masks (scalar
+    // bit tests instead of a dependent load per loop trip): bit h of store_mask = some offset asks for the dilation by h
+    // rows (they go to LDS slots in rising order of h), bit d of change_mask = hd[d] differs from hd[d - 1] (one slot down)
+    unsigned store_mask, change_mask;
+};
+
+template <typename Epi>
+__global__ void __launch_bounds__(RBIT_THREADS) reach_bits_kernel(const unsigned *__restrict__ bits, const int *__restrict__ any_bg,
+                                                                  Epi epi, unsigned long long *__restrict__ count, ReachTab tab,
+                                                                  int H, int W, int nch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned rb_lds[];  // [nslots][RBIT_THREADS] dilated words, then [RBIT_THREADS] verdicts
+    unsigned *acc_lds = rb_lds + tab.nslots * RBIT_THREADS;
+    const int b = blockIdx.z, ch = blockIdx.y, c0 = blockIdx.x * tab.tc;
+    const int t = threadIdx.x, c = c0 - RBIT_HALO + t;
+    // (1) the column's zero bits in the word rows above, here and below (nothing outside the frame is a zero pixel)
+    unsigned w0 = 0, w1 = 0, w2 = 0;
+    {
+        const int cc = min(max(c, 0), W - 1);
+        const bool col_in = c >= 0 && c < W;
+        const int64_t base = (int64_t)b * nch * W + cc;
+        const unsigned r0w = bits[base + rowoff(max(ch - 1, 0), W)], r1w = bits[base + rowoff(ch, W)],
+                       r2w = bits[base + rowoff(min(ch + 1, nch - 1), W)];
+        const int rows_last = H - (nch - 1) * EDT_CH;  // rows of the frame's last word
+        const unsigned v_last = rows_last >= 32 ? 0xFFFFFFFFu : ((1u << rows_last) - 1u);
+        if (col_in) {
+            w1 = ~r1w & (ch == nch - 1 ? v_last : 0xFFFFFFFFu);
+            if (ch > 0) w0 = ~r0w;
+            if (ch + 1 < nch) w2 = ~r2w & (ch + 1 == nch - 1 ? v_last : 0xFFFFFFFFu);
+        }
+    }
+    {
+        int slot = 0;
+        for (int h = 0; h <= tab.D; ++h) {
+            if ((tab.store_mask >> h) & 1u) rb_lds[(slot++) * RBIT_THREADS + t] = w1;
+            // one more row either way (the outer words lose a row of context per step: 31 steps never reach the middle word)
+            const unsigned n1 = w1 | __builtin_amdgcn_alignbit(w1, w0, 31) | __builtin_amdgcn_alignbit(w2, w1, 1);
+            const unsigned n0 = w0 | (w0 << 1) | __builtin_amdgcn_alignbit(w1, w0, 1);
+            const unsigned n2 = w2 | __builtin_amdgcn_alignbit(w2, w1, 31) | (w2 >> 1);
+            w0 = n0; w1 = n1; w2 = n2;
+        }
+    }
+    __syncthreads();
+    // (2) the union over the column offsets
+    if (t >= RBIT_HALO && t < RBIT_HALO + tab.tc) {
+        int slot = tab.nslots - 1;  // offset 0 asks for the largest dilation
+        unsigned acc = rb_lds[slot * RBIT_THREADS + t];
+        for (int d = 1; d <= tab.D; ++d) {
+            slot -= (int)((tab.change_mask >> d) & 1u);
+            const unsigned *row = rb_lds + slot * RBIT_THREADS + t;
+            acc |= row[-d] | row[d];
+        }
+        acc_lds[t] = acc;
+    }
+    __syncthreads();
+    // (3) verdict bits -> output bytes
+    const bool anybg = any_bg[b] != 0;
+    const int64_t fbase = (int64_t)b * H * W;
+    unsigned long long cnt = 0;
+    const bool wide = anybg && (W & 3) == 0 && ((uintptr_t)epi.out & 3) == 0 && (!Epi::kInput || ((uintptr_t)epi.input() & 3) == 0);
+    if (wide) {
+        // thread = (group of 8 rows, quad of columns): the quad's four verdict words once, then eight 4-byte loads in one batch
+        const int QUADS = tab.tc / 4;
+        const int g = t / QUADS, q = t % QUADS, cq = c0 + 4 * q;
+        if (g < 4 && cq < W) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(acc_lds + RBIT_HALO + 4 * q);
+            // the eight rows' bits of the four columns, one byte per column
+            const unsigned m = ((a.x >> (8 * g)) & 255u) | (((a.y >> (8 * g)) & 255u) << 8) | (((a.z >> (8 * g)) & 255u) << 16) |
+                               (((a.w >> (8 * g)) & 255u) << 24);
+            const int rr0 = ch * EDT_CH + 8 * g;
+            unsigned z4[8];
+            if (Epi::kInput) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    z4[jj] = *reinterpret_cast<const unsigned *>(epi.input() + fbase + rowoff(min(rr0 + jj, H - 1), W) + cq);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                if (rr0 + jj < H) {
+                    const unsigned w4 = (m >> jj) & 0x01010101u;
+                    *reinterpret_cast<unsigned *>(epi.out + fbase + rowoff(rr0 + jj, W) + cq) = epi.decide4(Epi::kInput ? z4[jj] : 0u, w4, cnt);
+                }
+        }
+    } else if (t < tab.tc && c0 + t < W) {
+        // ragged widths, unaligned images, and frames without any zero pixel (the verdict is then the epilogue's own
+        // business per pixel: scipy's virtual zero pixel): a column per thread, byte by byte
+        const unsigned a = acc_lds[RBIT_HALO + t];
+        const int cc = c0 + t;
+        for (int j = 0; j < EDT_CH; ++j) {
+            const int r = ch * EDT_CH + j;
+            if (r >= H) break;
+            const int64_t i = fbase + rowoff(r, W) + cc;
+            epi.out[i] = epi.decide(Epi::kInput ? epi.input()[i] : (uint8_t)0, ((a >> j) & 1u) != 0, anybg, r, cc, cnt);
+        }
+    }
+    if (count) {
+        // ONE atomic per block that counted anything: a frame's blocks all add to the same word, and same-address atomics
+        // queue (one per wave -- 43 000 a launch on 64 words -- made this kernel 195 us instead of 60)
+        __shared__ unsigned long long wsum[RBIT_THREADS / WAVE];
+        for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (lane_id() == 0) wsum[t / WAVE] = cnt;
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long s = 0;
+            for (int w = 0; w < (int)(blockDim.x / WAVE); ++w) s += wsum[w];
+            if (s) atomicAdd(&count[b], s);
+        }
+    }
+}
+
 struct EdtWs {
     unsigned *bits;
     uint16_t *up, *dn;
@@ -533,13 +681,55 @@ static int edt_run(Fg fg, Epi epi, unsigned long long *count, int B, int H, int 
     dim3 g1((W + 255) / 256, ws.nch, B);
     bool wide = false;
     if constexpr (Fg::kBytes) wide = (W & 3) == 0 && ((uintptr_t)fg.p & 3) == 0 && ((uintptr_t)ws.bits & 15) == 0;
+    // a threshold epilogue with a reach of at most 31 pixels runs on the bit words alone (reach_bits_kernel): no carries
+    bool bit_path = false;
+    ReachTab tab{};
+    if constexpr (Epi::kThreshold) {
+        const int R2 = epi.R2();
+        int D = (int)sqrt((double)R2);
+        while (D * D > R2) --D;
+        while ((D + 1) * (D + 1) <= R2) ++D;
+        if (PCSEG_EDT_REACH_BITS && D <= RBIT_MAXD) {
+            bit_path = true;
+            tab.D = D;
+            tab.nslots = 0;
+            tab.store_mask = tab.change_mask = 0;
+            int prev = -1;
+            for (int d = 0; d <= D; ++d) {
+                int h = (int)sqrt((double)(R2 - d * d));
+                while (h * h > R2 - d * d) --h;
+                while ((h + 1) * (h + 1) <= R2 - d * d) ++h;
+                if (h != prev) {
+                    ++tab.nslots;
+                    tab.store_mask |= 1u << h;
+                    if (d > 0) tab.change_mask |= 1u << d;
+                }
+                prev = h;
+            }
+        }
+    }
+    int *bits_any = bit_path ? ws.any_bg : nullptr;  // (the carry pass sets the flag on the other paths)
     if (wide) {
         if constexpr (Fg::kBytes)
-            PCSEG_LAUNCH((edt_bits4_kernel<Fg>), dim3((W / 4 + 255) / 256, ws.nch, B), dim3(256), 0, s, fg, ws.bits, H, W, ws.nch);
+            PCSEG_LAUNCH((edt_bits4_kernel<Fg>), dim3((W / 4 + 255) / 256, ws.nch, B), dim3(256), 0, s, fg, ws.bits, bits_any, H, W, ws.nch);
     } else {
-        PCSEG_LAUNCH((edt_bits_kernel<Fg>), g1, dim3(256), 0, s, fg, ws.bits, H, W, ws.nch);
+        PCSEG_LAUNCH((edt_bits_kernel<Fg>), g1, dim3(256), 0, s, fg, ws.bits, bits_any, H, W, ws.nch);
     }
     PCSEG_CHECK_LAUNCH();
+    if constexpr (Epi::kThreshold) {
+        if (bit_path) {
+            const size_t bytes = (size_t)(tab.nslots + 1) * RBIT_THREADS * sizeof(unsigned);
+            if (bytes > 64 * 1024)
+                PCSEG_CHECK_HIP(hipFuncSetAttribute((const void *)reach_bits_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            const int nblk = (W + RBIT_TC - 1) / RBIT_TC;
+            tab.tc = std::min(RBIT_TC, (((W + nblk - 1) / nblk) + 3) & ~3);
+            const int threads = (tab.tc + 2 * RBIT_HALO + WAVE - 1) / WAVE * WAVE;  // whole waves; the rest of the 512 would idle
+            PCSEG_LAUNCH((reach_bits_kernel<Epi>), dim3((W + tab.tc - 1) / tab.tc, ws.nch, B), dim3(threads), bytes, s,
+                         (const unsigned *)ws.bits, (const int *)ws.any_bg, epi, count, tab, H, W, ws.nch);
+            PCSEG_CHECK_LAUNCH();
+            return PCSEG_OK;
+        }
+    }
     PCSEG_LAUNCH(edt_carry_kernel, dim3((W + 255) / 256, B), dim3(256), 0, s, ws.bits, ws.up, ws.dn, ws.any_bg, H, W, ws.nch);
     PCSEG_CHECK_LAUNCH();
     dim3 g2((H + EDT_RB - 1) / EDT_RB, B);

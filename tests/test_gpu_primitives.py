@@ -548,3 +548,26 @@ def test_threshold_rows_skip_chunks_out_of_reach(ops):
         got = host(ops.dilate_disk(dev(cm), 1 << 3, rad))
         for i in range(4):
             np.testing.assert_array_equal(got[i].astype(bool), orc.binary_dilation_disk(cm[i] == 3, rad))
+
+
+def test_threshold_on_bit_words_shapes_and_radii(ops):
+    """The threshold epilogues with a reach of at most 31 pixels run on the bit words (reach_bits_kernel): ragged widths
+    (byte path), widths of one, two and three column blocks, heights that end inside a bit word, radii 0 .. 31 and the
+    first radius that takes the row-block pass again (32), zero pixels at block and word borders, a frame without any."""
+    for (h, w, p) in [(33, 45, 0.02), (95, 450, 0.004), (64, 1347, 0.001), (40, 900, 0.002), (130, 452, 0.0005), (5, 3, 0.3)]:
+        z = (RNG.random((3, h, w)) < p).astype(np.uint8) * 3
+        z[1] = 0
+        for (r, c) in [(0, 0), (h - 1, w - 1), (31 % h, 447 % w), (32 % h, 448 % w), (h // 2, (w // 2) & ~3)]:
+            z[1][r, c] = 3
+        z[2] = 1  # no zero pixel of the set at all
+        for rad in (0, 1, 2, 7, 20, 31, 32):
+            got = host(ops.dilate_disk(dev(z), 1 << 3, rad))
+            for i in range(3):
+                np.testing.assert_array_equal(got[i].astype(bool), orc.binary_dilation_disk(z[i] == 3, rad), err_msg="%s r=%d f=%d" % ((h, w), rad, i))
+        cm = np.where(z == 3, 3, RNG.integers(1, 3, z.shape)).astype(np.uint8)
+        cm[2, 0, :2] = 1
+        out, area = ops.fill_particle(dev(cm), 3, 1, 3, 20, 2)
+        for i in range(3):
+            exp, ov = orc.fill_particle_area(cm[i], 3, 1, 3)
+            np.testing.assert_array_equal(host(out)[i], exp)
+            assert int(area[i]) == ov
