@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256, PCSEG_FRONTEND_OCC) classmap_median_ccl_k
 {
     // the histogram words are dead once the medians are out: the union-find parents take their place (18 KB per block
     // instead of 26: 8 blocks per CU -- the kernel waits on memory most of the time and wants the waves)
-    __shared__ __attribute__((aligned(16))) uint32_t hot[MED_LH * MED_LW];  // 1 << (5 * class) of the tile + halo
+    __shared__ __attribute__((aligned(16))) uint32_t hot[MED_LH * MED_LW];  // 1 << (6 * (class - 1)) of the tile + halo
     __shared__ int key[CCL_TILE];
     static_assert(sizeof(uint32_t) * MED_LH * MED_LW >= sizeof(int) * CCL_TILE, "parents fit the histogram words");
     int *par = reinterpret_cast<int *>(hot);
@@ -83,10 +83,10 @@ __global__ void __launch_bounds__(256, PCSEG_FRONTEND_OCC) classmap_median_ccl_k
                 const int lr = i / (MED_TW / 4), q = i % (MED_TW / 4);
                 const unsigned a = cls4[t];
                 uint32_t *dst = hot + lr * MED_LW + 2 + 4 * q;
-                dst[0] = 1u << (5 * (a & 255u));
-                dst[1] = 1u << (5 * ((a >> 8) & 255u));
-                dst[2] = 1u << (5 * ((a >> 16) & 255u));
-                dst[3] = 1u << (5 * (a >> 24));
+                dst[0] = 1u << (6 * (a & 255u) - 6);
+                dst[1] = 1u << (6 * ((a >> 8) & 255u) - 6);
+                dst[2] = 1u << (6 * ((a >> 16) & 255u) - 6);
+                dst[3] = 1u << (6 * (a >> 24) - 6);
             }
         }
         for (int i = threadIdx.x; i < MED_LH * 4; i += 256) {  // the two halo columns either side
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256, PCSEG_FRONTEND_OCC) classmap_median_ccl_k
             int rr = r0 + lr - 2, cc = c0 + lc - 2;
             if (rr < 0 || rr >= H) rr = reflect_idx(rr, H);
             if (cc < 0 || cc >= W) cc = reflect_idx(cc, W);
-            hot[lr * MED_LW + lc] = 1u << (5 * class1(fr, C, n, rowoff(rr, W) + cc));
+            hot[lr * MED_LW + lc] = 1u << (6 * class1(fr, C, n, rowoff(rr, W) + cc) - 6);
         }
     } else {
         for (int i = threadIdx.x; i < MED_LH * (MED_TW + 4); i += 256) {
@@ -102,28 +102,36 @@ __global__ void __launch_bounds__(256, PCSEG_FRONTEND_OCC) classmap_median_ccl_k
             int rr = r0 + lr - 2, cc = c0 + lc - 2;
             if (rr < 0 || rr >= H) rr = reflect_idx(rr, H);
             if (cc < 0 || cc >= W) cc = reflect_idx(cc, W);
-            hot[lr * MED_LW + lc] = 1u << (5 * class1(fr, C, n, rowoff(rr, W) + cc));
+            hot[lr * MED_LW + lc] = 1u << (6 * class1(fr, C, n, rowoff(rr, W) + cc) - 6);
         }
     }
     __syncthreads();
-    // (2) medians -> the denoised map (global) and the union-find keys (LDS; 0 = outside the frame, classes are >= 1)
+    // (2) medians -> the denoised map (global) and the union-find keys (LDS; 0 = outside the frame, classes are >= 1).
+    // A thread takes two 4-pixel strips, one below the other (MED_TW / 4 strips x MED_TH / 2 row pairs = 256 threads).
     uint8_t *dst = z + (int64_t)b * n;
-    for (int s = threadIdx.x; s < (MED_TW / 4) * MED_TH; s += 256) {
-        const int lr = s / (MED_TW / 4), lc = (s % (MED_TW / 4)) * 4;
-        const int r = r0 + lr, c = c0 + lc;
-        uint32_t med[4] = {0, 0, 0, 0};
+    static_assert((MED_TW / 4) * (MED_TH / 2) == 256, "one pair of strips per thread");
+    {
+        const int s = threadIdx.x;
+        const int lr = 2 * (s / (MED_TW / 4)), lc = (s % (MED_TW / 4)) * 4;
+        const int c = c0 + lc;
+        uint32_t med[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #if defined(PCSEG_EXP_FRONTEND) && (PCSEG_EXP_FRONTEND & 1)  // (ablation builds, profiles/r04/time_ops.py: the kernel's time without a phase)
-        med[0] = med[1] = med[2] = med[3] = 1 + ((lr + lc) & 1);
+        for (int j = 0; j < 4; ++j) med[0][j] = med[1][j] = 1 + ((lr + lc) & 1);
 #else
-        if (r < H && c < W) median5_hot_strip(hot, lr, lc, med);
+        if (r0 + lr < H && c < W) median5_hot6_strip2(hot, lr, lc, med[0], med[1]);
 #endif
 #pragma unroll
-        for (int j = 0; j < 4; ++j) key[lr * CCL_TW + lc + j] = (r < H && c + j < W) ? (int)med[j] : 0;
-        if (r < H && c < W) {
-            if (c + 3 < W && (W & 3) == 0) {
-                *reinterpret_cast<uint32_t *>(dst + rowoff(r, W) + c) = med[0] | (med[1] << 8) | (med[2] << 16) | (med[3] << 24);
-            } else {
-                for (int j = 0; j < 4 && c + j < W; ++j) dst[rowoff(r, W) + c + j] = (uint8_t)med[j];
+        for (int half = 0; half < 2; ++half) {
+            const int r = r0 + lr + half;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) key[(lr + half) * CCL_TW + lc + j] = (r < H && c + j < W) ? (int)med[half][j] : 0;
+            if (r < H && c < W) {
+                if (c + 3 < W && (W & 3) == 0) {
+                    *reinterpret_cast<uint32_t *>(dst + rowoff(r, W) + c) =
+                        med[half][0] | (med[half][1] << 8) | (med[half][2] << 16) | (med[half][3] << 24);
+                } else {
+                    for (int j = 0; j < 4 && c + j < W; ++j) dst[rowoff(r, W) + c + j] = (uint8_t)med[half][j];
+                }
             }
         }
     }

@@ -45,6 +45,63 @@ __device__ __forceinline__ void median5_hot_strip(const uint32_t *hot, int lr, i
     }
 }
 
+// The same for CLASSES 1 .. 5 in 6-bit fields (hot[] holds 1 << (6 * (class - 1)): five fields, 30 bits).  The spare bit of a
+// field turns the five "cumulative count < 13" tests of a pixel into one subtraction: 44 - count is at least 32 exactly when
+// count <= 12 (no borrow crosses a field: counts are at most 25), so the median is 1 + the number of fields 0 .. 3 whose bit 5
+// is set -- one multiply, one subtract, one and, one bit count per pixel instead of five extract / compare / add triples.
+__device__ __forceinline__ void median5_hot6_strip(const uint32_t *hot, int lr, int lc, uint32_t med[4])
+{
+    uint32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dr = 0; dr < 5; ++dr) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(hot + (lr + dr) * MED_LW + lc);
+        const uint4 a = row[0], bq = row[1];
+        col[0] += a.x; col[1] += a.y; col[2] += a.z; col[3] += a.w;
+        col[4] += bq.x; col[5] += bq.y; col[6] += bq.z; col[7] += bq.w;
+    }
+    uint32_t w = col[0] + col[1] + col[2] + col[3] + col[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j > 0) w += col[j + 4] - col[j - 1];
+        const uint32_t cum = w * 0x01041041u;            // field k: pixels of the window with a class <= k + 1
+        const uint32_t below = 0x2CB2CB2Cu - cum;        // 44 in every field (fields 0 .. 4), minus the counts
+        med[j] = 1u + __popc(below & 0x00820820u);       // bit 5 of the fields 0 .. 3
+    }
+}
+
+// Two strips, one below the other (rows lr and lr + 1): six rows of words are read ONCE, all twelve 16-byte reads in flight
+// together, and the lower strip's column sums are the upper one's minus row lr plus row lr + 5.
+__device__ __forceinline__ void median5_hot6_strip2(const uint32_t *hot, int lr, int lc, uint32_t med0[4], uint32_t med1[4])
+{
+    uint4 a[6], bq[6];
+#pragma unroll
+    for (int dr = 0; dr < 6; ++dr) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(hot + (lr + dr) * MED_LW + lc);
+        a[dr] = row[0];
+        bq[dr] = row[1];
+    }
+    uint32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dr = 0; dr < 5; ++dr) {
+        col[0] += a[dr].x; col[1] += a[dr].y; col[2] += a[dr].z; col[3] += a[dr].w;
+        col[4] += bq[dr].x; col[5] += bq[dr].y; col[6] += bq[dr].z; col[7] += bq[dr].w;
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) {
+            col[0] += a[5].x - a[0].x; col[1] += a[5].y - a[0].y; col[2] += a[5].z - a[0].z; col[3] += a[5].w - a[0].w;
+            col[4] += bq[5].x - bq[0].x; col[5] += bq[5].y - bq[0].y; col[6] += bq[5].z - bq[0].z; col[7] += bq[5].w - bq[0].w;
+        }
+        uint32_t w = col[0] + col[1] + col[2] + col[3] + col[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j > 0) w += col[j + 4] - col[j - 1];
+            const uint32_t below = 0x2CB2CB2Cu - w * 0x01041041u;
+            (half ? med1 : med0)[j] = 1u + __popc(below & 0x00820820u);
+        }
+    }
+}
+
 // Union-find of one 64x32 tile in LDS: key[] (0 = background, equal non-zero keys connect) -> par[] such that
 // find_lds(par, i) is the tile-local root (smallest index) of pixel i; par[i] = -1 for background.  Row runs are
 // pre-linked without atomics (a wave covers one 64-pixel tile row per trip, run heads come from a ballot, every pixel
