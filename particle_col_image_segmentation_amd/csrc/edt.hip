@@ -7,6 +7,10 @@
 // as uint16, and the horizontal pass is an expanding search that stops as soon
 // as k*k >= best (exact: the candidate at offset k is >= k*k).  HBM traffic is
 // the input read plus the int32 (or uint8) result write.
+//
+// The THRESHOLD operators with a reach of at most 31 pixels (every call of the reference: disk(2), disk(20), distance < 2) never
+// form a distance: reach_bits_kernel dilates the bit words themselves (see there); the row-block pass with its prefix scans
+// (edt_reach_kernel) serves larger radii.
 #include <type_traits>
 
 #include "common.h"
