@@ -9,6 +9,26 @@
 // fallback walks rows: one wave per 64-pixel row segment, label runs from a ballot, closed-form run sums.
 #include "common.h"
 
+#ifndef PCSEG_SUMS_NT_LOADS
+// A/B (profiles/r04/ab_logs/r5a_*): the fused sums pass 378 us with non-temporal plane loads against 389-394 with plain ones; the
+// front end, whose tiles share halo rows through L2, lost a quarter with them (526 us against 426) and keeps plain loads
+#define PCSEG_SUMS_NT_LOADS 1
+#endif
+#ifndef PCSEG_LABELS_NT_LOADS
+#define PCSEG_LABELS_NT_LOADS 0  // A/B: the label images of the region passes (each read once per pass) as non-temporal loads too
+#endif
+namespace pcseg {
+__device__ __forceinline__ int4 ld_labels4(const int *p)
+{
+#if PCSEG_LABELS_NT_LOADS
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    const i4v t = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(p));
+    return make_int4(t.x, t.y, t.z, t.w);
+#else
+    return *reinterpret_cast<const int4 *>(p);
+#endif
+}
+}  // namespace pcseg
 namespace pcseg {
 
 constexpr int RED_SLOTS = 256;
@@ -516,12 +536,12 @@ __global__ void __launch_bounds__(256, PCSEG_STATS_OCC) region_stats_col_kernel(
     int cur[4] = {0, 0, 0, 0}, start[4] = {0, 0, 0, 0};
     int parked_label[4] = {0, 0, 0, 0}, parked_rows[4] = {0, 0, 0, 0};  // first row | end row << 16 (rows < 2^15)
     const int *at = lab + rowoff(r0, W) + (inside ? c : 0);
-    int4 l4n = inside ? *reinterpret_cast<const int4 *>(at) : make_int4(0, 0, 0, 0);
+    int4 l4n = inside ? ld_labels4(at) : make_int4(0, 0, 0, 0);
     for (int r = r0; r < r1; ++r) {
         const int4 l4 = l4n;
         landed(l4);
         at += W;
-        if (inside && r + 1 < r1) l4n = *reinterpret_cast<const int4 *>(at);
+        if (inside && r + 1 < r1) l4n = ld_labels4(at);
         const int ll[4] = {l4.x, l4.y, l4.z, l4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -674,12 +694,21 @@ __global__ void __launch_bounds__(256, (NC <= 5 && !STATS_B) ? 3 : 2) region_sum
             a4n = make_int4(0, 0, 0, 0);
             b4n = make_int4(0, 0, 0, 0);
             if (r < r1) {
-                a4n = *reinterpret_cast<const int4 *>(la + at);
-                b4n = *reinterpret_cast<const int4 *>(lb + at);
+                a4n = ld_labels4(la + at);
+                b4n = ld_labels4(lb + at);
                 cwn = *reinterpret_cast<const unsigned *>(cbytes + at);
 #pragma unroll
                 for (int k = 0; k < NC; ++k)
+#if PCSEG_SUMS_NT_LOADS  // the planes are read once by this pass and not again: non-temporal loads (no reuse to keep in the caches)
+                    {
+                        typedef float f4v __attribute__((ext_vector_type(4)));
+                        f4v t = {0.f, 0.f, 0.f, 0.f};
+                        if (EXACT || k < C) t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(pl + (int64_t)k * n + at));
+                        vn[k] = make_float4(t.x, t.y, t.z, t.w);
+                    }
+#else
                     vn[k] = (EXACT || k < C) ? *reinterpret_cast<const float4 *>(pl + (int64_t)k * n + at) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
                 at += W;
             }
         };
