@@ -84,6 +84,12 @@ def parse_args():
     ap.add_argument("--levels", type=int, default=0,
                     help="NOT the headline workload: quantise the boundary plane to k/LEVELS (random-forest-like vote "
                          "fractions); every frame then floods through ties and takes the watershed's exact path")
+    ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
+                    help="how the timed steps are launched.  auto (default): the SETUP phase, before warm-up, runs a few untimed "
+                         "steps both ways -- eager launches from eight host threads, and hipGraph replays with four in flight from "
+                         "one host thread -- and the timed region uses the faster; the same chain either way.  (Eager launches "
+                         "overlap a little better on a quiet host; on a busy one the eight launch threads fall behind and "
+                         "replays win by 15 %%: profiles/r04/ab_logs/r5d_*.)")
     ap.add_argument("--watershed-mode", type=int, default=0,
                     help="profiling aid for ABLATION builds (libraries that skip a phase: wrong labels, right timing): 2 = frames "
                          "the proof fails on are reported, not recomputed by the exact flood.  The headline runs mode 0")
@@ -290,8 +296,9 @@ def _timing_pass(lib, fn, sync):
 
 
 def graph_leg(args, stack, cell_types, eager_ms):
-    """The same chain as ONE hipGraph replay per step (FramePipeline(graph=True), two graphs in flight): what a host that
-    cannot afford eight launch threads gets.  Not `value`: eager launches from many streams overlap better."""
+    """The same chain as ONE hipGraph replay per step (FramePipeline(graph=True) as the library ships it: two graphs in flight):
+    what a host that cannot afford eight launch threads gets.  `fraction_of_headline` compares it with the timed region,
+    whichever way that was launched (config.launch)."""
     import torch
     from particle_col_image_segmentation_amd.pipeline import FramePipeline
     pipe = FramePipeline(cell_types, graph=True)
@@ -307,7 +314,7 @@ def graph_leg(args, stack, cell_types, eager_ms):
     B, H, W = int(stack.shape[0]), int(stack.shape[2]), int(stack.shape[3])
     out = {"launch": "one hipGraph replay per step, %d in flight, one host thread" % pipe.lanes, "steps": args.graph_leg_steps,
            "ms_per_step": round(ms, 3), "value": round(B * H * W / ms / 1e3, 1), "unit": "Mpixels/s",
-           "fraction_of_eager": round(eager_ms / ms, 3), "tie_fallback_frames": int(res["tie_flags"].sum().item())}
+           "fraction_of_headline": round(eager_ms / ms, 3), "tie_fallback_frames": int(res["tie_flags"].sum().item())}
     del pipe, res
     torch.cuda.empty_cache()
     return out
@@ -415,9 +422,42 @@ def _run(args):
     stack = synth.gen_batch_torch(10_000 + rank * B, B, H, W, dev)
     if args.levels > 0:
         stack[:, 3] = torch.round(stack[:, 3] * args.levels) / args.levels
-    graph = bool(args.graph)
-    pipe = FramePipeline(ct, overlap=not args.serial, lanes=args.lanes or None, multi_stream=not args.single_class_stream,
-                         graph=graph, merged=not args.no_merge, watershed_mode=args.watershed_mode)
+    graph = bool(args.graph) or args.launch == "graph"
+    launch_probe = None
+    auto = args.launch == "auto" and not args.graph and not args.serial and not args.lanes and not args.single_class_stream
+    if auto:
+        # SETUP: both launch modes, primed, then timed over a few untimed steps each (alternating, the better of two); the timed
+        # region below runs the faster one.  With several ranks the slowest rank's figures decide, so every rank chooses alike.
+        pipe_e = FramePipeline(ct, merged=not args.no_merge, watershed_mode=args.watershed_mode)
+        pipe_g = FramePipeline(ct, graph=True, lanes=4, merged=not args.no_merge, watershed_mode=args.watershed_mode)
+        for p_, n_ in ((pipe_e, max(2, pipe_e.lanes)), (pipe_g, pipe_g.lanes + 2)):
+            for _ in range(n_):
+                p_.run(stack)
+            p_.synchronize()
+
+        def probe_ms(p_, n_=8):
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(n_):
+                p_.run(stack)
+            p_.synchronize()
+            return 1e3 * (time.perf_counter() - t_) / n_
+
+        te, tg = probe_ms(pipe_e), probe_ms(pipe_g)
+        te, tg = min(te, probe_ms(pipe_e)), min(tg, probe_ms(pipe_g))
+        if use_dist:
+            t = torch.tensor([te, tg], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            te, tg = float(t[0].item()), float(t[1].item())
+        graph = tg < te
+        launch_probe = {"eager_8_host_threads": round(te, 3), "graph_replays_4_in_flight": round(tg, 3)}
+        pipe = pipe_g if graph else pipe_e
+        del pipe_e, pipe_g, p_
+        torch.cuda.empty_cache()
+    else:
+        pipe = FramePipeline(ct, overlap=not args.serial, lanes=args.lanes or (4 if (graph and args.launch == "graph") else None),
+                             multi_stream=not args.single_class_stream, graph=graph, merged=not args.no_merge,
+                             watershed_mode=args.watershed_mode)
     res = None
     # setup (not warmup): in graph mode the first pass through each lane captures its graph (one plain run + the capture);
     # in eager mode two priming passes fill torch's caching allocator with every workspace block.  Then W untimed warmup
@@ -497,8 +537,11 @@ def _run(args):
             refs, _, _ = parity.run_oracle(stack[[0, B - 1]].cpu().numpy(), ct, merged=True, processes=2)
             checked = parity.compare(res, [0, B - 1], refs, sums_rtol=1e-6)
     e2e_block = None
+    legs_pipe = None
     if not args.serial and not args.no_end_to_end:
-        e2e_block = end_to_end_leg(args, stack, ct, pipe, dev, world, world * B * H * W * args.steps / elapsed / 1e6,
+        # (the dataset legs refill rotating input buffers: they run the eager pipeline whichever way the timed region was launched)
+        legs_pipe = pipe if not graph else FramePipeline(ct, merged=not args.no_merge, watershed_mode=args.watershed_mode)
+        e2e_block = end_to_end_leg(args, stack, ct, legs_pipe, dev, world, world * B * H * W * args.steps / elapsed / 1e6,
                                    refs=cpu_refs if world == 1 else None)
     if rank == 0:
         kernels, tiles_i, launches_i, steps_i = insitu
@@ -577,7 +620,8 @@ def _run(args):
                        "launch": ("one hipGraph replay per step, %d in flight" if graph else "eager launches from %d host threads") % pipe.lanes,
                        "tie_fallback_frames_last_step": tie_frames, "reference_nan_frames_rank0": nan_frames,
                        "gathered_roi_rows": n_rois, "table_assembly_ms_last_batch": round(table_ms, 3),
-                       "roi_table_all_gather_ms": round(gather_ms, 3)},
+                       "roi_table_all_gather_ms": round(gather_ms, 3),
+                       "launch_probe_ms_per_step": launch_probe},
             "roofline": dict({"bound": "hbm", "kernel": short if short != "ws_relax_kernel" else "ws_relax_kernel + ws_relax_list_kernel",
                               "algorithmic_bytes_per_pixel": bpp},
                              **{k: v for k, v in main_block.items() if k != "how"},
@@ -599,8 +643,16 @@ def _run(args):
         if checked is not None:
             out["config"]["parity_checked_frames"] = checked
         out["end_to_end"] = e2e_block
+        if graph and launch_probe is not None:
+            # the timed region ran as graph replays: their private pools go back before the other legs allocate (see
+            # secondary_leg), and those legs take the eager pipeline
+            import gc
+            res = None
+            pipe = legs_pipe if legs_pipe is not None else FramePipeline(ct, merged=not args.no_merge, watershed_mode=args.watershed_mode)
+            gc.collect()
+            torch.cuda.empty_cache()
         if world == 1 and not args.levels and not args.serial:
-            if args.graph_leg_steps > 0 and not graph:
+            if args.graph_leg_steps > 0 and not (graph and launch_probe is None):
                 out["graph_replay"] = graph_leg(args, stack, ct, 1e3 * elapsed / args.steps)
             if args.batch64_frames > 0:
                 out["batch64"] = batch64_leg(args, stack, ct)
