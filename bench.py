@@ -11,10 +11,11 @@ over one batch of 64 frames of 1024x1024x5 float32 that is already resident in H
 independent, so N ranks each process their own batch (weak scaling, no data-path collective); the only exchange is
 the RCCL all-gather of the ROI table, done once after the timed region.
 
-The timed region carries no instrumentation (no event records, no counter reads).  By default the batches are launched
-eagerly from 8 host threads with five streams each -- measured faster than hipGraph replay on this chain (replays of
-different graphs overlap less than eager launches from many streams do; the run reports the graph figure next to the
-headline as `graph_replay`, and `--graph` makes it the timed mode).  The JSON line carries `roofline` (dominant kernel by
+The timed region carries no instrumentation (no event records, no counter reads).  How its steps are LAUNCHED is settled in the
+setup phase (`--launch auto`, the default): eight untimed steps, twice, as eager launches from 8 host threads with five streams
+each and as hipGraph replays with four in flight from one host thread; the timed region runs the faster (`config.launch`,
+`config.launch_probe_ms_per_step`).  On a quiet host the two are within 3 %; on a busy one the eight launch threads fall behind
+and replays win by 15 %.  `--launch eager|graph` fixes the mode.  The JSON line carries `roofline` (dominant kernel by
 serial time; HIP events on the launch stream in two extra single-stream steps right after the timed region -- the
 reproducible figure -- with the same kernel's duration while 8 batches share the chip as `in_flight`, and `stage_frac` =
 the watershed stage's compulsory 13 B/px over the serial time of all its kernels) and `cpu_baseline` (the CPU oracle timed
